@@ -1,0 +1,222 @@
+/*
+ * y5hip.h - C ABI of liby5hip.so: the MI355X (gfx950) kernels behind the YOLOv5-v2.0
+ * inference hot path  conv forward -> Detect decode -> non_max_suppression.
+ *
+ * The reference has no FFI of its own for this path: it calls torch / torchvision tensor
+ * operators from Python.  Every entry point below therefore cites the reference call site whose
+ * arithmetic it replaces (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - plain C, no exceptions across the boundary; every function returns 0 on success or a
+ *     negative Y5_E* code, with a human-readable message available from y5_last_error()
+ *     (thread-local).
+ *   - every pointer named in a descriptor is DEVICE memory owned by the caller, except where a
+ *     comment says "host".  The library allocates no device memory and frees none.
+ *   - every call is asynchronous on the hipStream_t passed as `stream` (NULL = the default
+ *     stream) and uses the calling thread's current HIP device.
+ *   - activations are NHWC fp16 ("pixel-major"): element (b, y, x, c) of a tensor with pixel
+ *     pitch `ld` lives at  base + ((b*H + y)*W + x)*ld + c.  A tensor may be a channel slice of
+ *     a wider buffer (ld > channels), which is how concatenations are formed in place.
+ *     Channel counts and pitches are multiples of 8 (16-byte vectors); padding channels carry zeros.
+ */
+#ifndef Y5HIP_H
+#define Y5HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define Y5_OK 0
+#define Y5_EINVAL (-1)    /* bad argument / unsupported shape                     */
+#define Y5_EHIP (-2)      /* a HIP runtime call failed (message has the HIP error) */
+#define Y5_ENOMEM (-3)    /* host allocation failed                                */
+#define Y5_EWORKSPACE (-4) /* caller-provided workspace too small                  */
+
+typedef void* y5_stream_t; /* hipStream_t */
+
+/* Library version (major*10000 + minor*100 + patch). */
+int y5_version(void);
+/* Message of the last failing call on this thread ("" if none). The pointer stays valid until
+ * the next failing call on the same thread. */
+const char* y5_last_error(void);
+/* gcnArchName of the current device copied into buf (NUL-terminated, truncated to n). */
+int y5_device_arch(char* buf, int n);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution as implicit GEMM on MFMA (fp16 in, fp32 accumulate, fp16 out).
+ * Replaces: Conv.forward / Conv.fuseforward  models/common.py:26-30 (conv2d -> BatchNorm2d ->
+ * LeakyReLU(0.1), or conv2d+bias -> LeakyReLU after Model.fuse models/yolo.py:155-163),
+ * the plain 1x1 convs and the concat BatchNorm of BottleneckCSP  models/common.py:59-62,
+ * the residual add of Bottleneck  models/common.py:43, and the biased 1x1 head conv of Detect
+ * models/yolo.py:33.
+ *
+ * y[b,oy,ox,n] = post( sum_{r,q,c} x[b, oy*stride - pad + r, ox*stride - pad + q, c] * w[n, (r*k + q)*cin + c] )
+ * post(v): v = fp16(v + bias[n])            (bias may be NULL)
+ *          v = fp16(v*scale[n] + shift[n])  (only when scale != NULL; the folded BatchNorm)
+ *          v = fp16(v > 0 ? v : slope*v)    (only when act == Y5_ACT_LEAKY)
+ *          v = fp16(v + res[b,oy,ox,n])     (only when res != NULL)
+ * The intermediate fp16 roundings are the ones the reference's tensor-by-tensor evaluation
+ * performs in half precision.
+ * ------------------------------------------------------------------------------------------ */
+#define Y5_ACT_NONE 0
+#define Y5_ACT_LEAKY 1
+
+typedef struct y5_conv_desc {
+    const void* x;      /* input  (batch, h, w, cin) fp16, pixel pitch x_ld                         */
+    const void* w;      /* weights fp16 [w_rows][kpad]; row n holds k = (r*ksize+q)*cin + c, zero padded */
+    const float* bias;  /* [cout] fp32 or NULL                                                      */
+    const float* scale; /* [cout] fp32 or NULL                                                      */
+    const float* shift; /* [cout] fp32, required when scale != NULL                                 */
+    const void* res;    /* residual (batch, ho, wo, cout) fp16, pixel pitch res_ld, or NULL         */
+    void* y;            /* output (batch, ho, wo, cout) fp16, pixel pitch y_ld                      */
+    int32_t batch, h, w_in, cin, x_ld;
+    int32_t ho, wo, cout, y_ld, res_ld;
+    int32_t ksize, stride, pad; /* ksize in {1,3}; stride in {1,2}; pad = ksize/2                  */
+    int32_t kpad;               /* >= ksize*ksize*cin, multiple of 32                               */
+    int32_t w_rows;             /* >= cout, multiple of 128                                         */
+    int32_t act;                /* Y5_ACT_*                                                         */
+    float slope;                /* LeakyReLU negative slope (0.1 in the reference)                  */
+} y5_conv_desc;
+
+int y5_conv_f16(const y5_conv_desc* d, y5_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Input packing: NCHW fp16 image batch -> NHWC fp16, optionally with the Focus space-to-depth
+ * gather. Replaces: Focus.forward's four strided slices + cat  models/common.py:85-86
+ * (output channel q*c + ci, q = (row parity, col parity) in the order (0,0),(1,0),(0,1),(1,1)).
+ * focus = 0: y is (batch, h, w, y_ld), channels [c, y_ld) zero.
+ * focus = 1: y is (batch, h/2, w/2, y_ld), channels [4c, y_ld) zero; h and w must be even.
+ * ------------------------------------------------------------------------------------------ */
+int y5_pack_image_f16(const void* x_nchw, void* y_nhwc, int batch, int c, int h, int w, int focus, int y_ld,
+                      y5_stream_t stream);
+
+/* k x k max pooling, stride 1, padding k/2 with -inf (k odd, <= 13), on a channel slice.
+ * Replaces: nn.MaxPool2d(k, 1, k//2) inside SPP  models/common.py:72,76.  x and y may be
+ * different channel slices of the same buffer (the SPP concat) but must not overlap. */
+int y5_maxpool_f16(const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c, int k,
+                   y5_stream_t stream);
+
+/* 2x spatial upsampling of a channel slice into another (usually a concat) buffer.
+ * Replaces: nn.Upsample(None, 2, 'nearest' | 'bilinear') + Concat  models/yolov5s.yaml:30-31,
+ * models/yolov5s_ori.yaml:79-80.  mode 0 = nearest, 1 = bilinear with align_corners=False. */
+int y5_upsample2x_f16(const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c, int mode,
+                      y5_stream_t stream);
+
+/* Copy a channel slice (batch*h*w pixels, c channels) between pitched buffers.
+ * Replaces: Concat.forward  models/common.py:95-96 for operands that cannot be produced in place. */
+int y5_copy_channels_f16(const void* x, int x_ld, void* y, int y_ld, int64_t pixels, int c, y5_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Detect box decode for one pyramid level.
+ * Replaces: Detect.forward  models/yolo.py:34-46 (view/permute/contiguous, sigmoid, grid/anchor
+ * decode, per-level part of cat(z, 1)) and _make_grid  models/yolo.py:48-51.
+ * head: (batch, ny, nx, head_ld) fp16, channel a*no + o.
+ * x_out: (batch, na, ny, nx, no) fp16 raw head values (the reference's x[i]); may be NULL.
+ * z_out: (batch, z_rows_total, no) fp16; this level writes rows z_row0 + a*ny*nx + y*nx + x.
+ * Rounding order (half mode): s = fp16(sigmoid(v)); xy = fp16((fp32(fp16(2s - 0.5)) + grid) * stride);
+ * wh = fp16(fp16((2s)^2) * anchor); everything else s.
+ * ------------------------------------------------------------------------------------------ */
+#define Y5_MAX_ANCHORS 8
+typedef struct y5_decode_desc {
+    const void* head;
+    void* x_out;
+    void* z_out;
+    int32_t head_ld;
+    int32_t batch, ny, nx, na, no;
+    int32_t z_rows_total, z_row0;
+    float stride;
+    float anchor_wh[2 * Y5_MAX_ANCHORS]; /* pixel anchors (w,h) per anchor as stored in Detect.anchor_grid */
+} y5_decode_desc;
+
+int y5_detect_decode_f16(const y5_decode_desc* d, y5_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Batched non-maximum suppression.
+ * Replaces: non_max_suppression  utils/utils.py:564-645 for merge=False (confidence filter,
+ * conf = obj*cls, xywh2xyxy utils/utils.py:183-190, multi-label candidate expansion, optional
+ * class filter, per-class 4096-pixel box offset, torchvision.ops.boxes.nms call utils/utils.py:627,
+ * 300-detection cap).  torchvision's greedy NMS: visit boxes by descending score (stable: lower
+ * original index first among equal scores); a visited box is kept unless an earlier KEPT box has
+ * inter/(area_i + area_j - inter) > iou_thres, all in fp32 and compared in double.
+ *
+ * pred: (batch, n_rows, no) rows [cx, cy, w, h, obj, cls_0..]; dtype 0 = fp16, 1 = fp32.
+ * det: (batch, max_det, 6) fp32 rows [x1, y1, x2, y2, conf, cls], first count[b] rows valid, rest zero.
+ * kept_index (optional): (batch, max_det) int32, anchor_row*nc + cls of each kept detection.
+ * n_candidates (optional): (batch) int32, candidates that passed the confidence filter (uncapped).
+ * If n_candidates[b] > max_candidates the image was truncated to an arbitrary subset and the
+ * caller must retry with a larger capacity.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct y5_nms_desc {
+    const void* pred;
+    const uint8_t* class_keep; /* [nc] 1 = class allowed, or NULL = all (the `classes` argument) */
+    void* workspace;
+    float* det;
+    int32_t* count;
+    int32_t* kept_index;
+    int32_t* n_candidates;
+    size_t workspace_bytes;
+    double iou_thres;
+    float conf_thres;
+    int32_t pred_dtype;
+    int32_t batch, n_rows, no;
+    int32_t agnostic;
+    int32_t max_candidates; /* per-image candidate capacity */
+    int32_t max_det;        /* <= 1024; 300 in the reference */
+} y5_nms_desc;
+
+size_t y5_nms_workspace_bytes(int batch, int max_candidates);
+int y5_nms_batched(const y5_nms_desc* d, y5_stream_t stream);
+
+/* Greedy NMS of one box set, the drop-in for torchvision.ops.boxes.nms(boxes, scores, iou_thres)
+ * (call site utils/utils.py:627; also used by the merge=True branch utils/utils.py:630-639).
+ * boxes (n,4) fp32 corner boxes, scores (n) fp32.  keep (max_keep) int64 receives the kept indices
+ * in descending score order, keep_count[0] their number (<= max_keep).
+ * workspace: y5_nms_workspace_bytes(1, n) bytes. */
+int y5_nms_boxes_f32(const float* boxes, const float* scores, int n, double iou_thres, int64_t* keep,
+                     int32_t* keep_count, int max_keep, void* workspace, size_t workspace_bytes,
+                     y5_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Launch plans: a host-side list of the calls above, replayed with one C call per forward.
+ * Replaces: the Python module walk of Model.forward_once  models/yolo.py:107-130.
+ * Pointers inside the recorded descriptors are used as recorded, except pointers that were
+ * registered as "external slot k": those are replaced at run time by ext[k] + recorded offset
+ * (network input, per-call output tensors).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct y5_plan y5_plan;
+
+int y5_plan_create(y5_plan** out);
+void y5_plan_destroy(y5_plan* p);
+/* Declare that device address `base` stands for external slot `slot` (0..15) while recording. */
+int y5_plan_bind_slot(y5_plan* p, int slot, const void* base, size_t bytes);
+int y5_plan_add_conv(y5_plan* p, const y5_conv_desc* d);
+int y5_plan_add_pack_image(y5_plan* p, const void* x_nchw, void* y_nhwc, int batch, int c, int h, int w, int focus,
+                           int y_ld);
+int y5_plan_add_maxpool(y5_plan* p, const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c,
+                        int k);
+int y5_plan_add_upsample2x(y5_plan* p, const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c,
+                           int mode);
+int y5_plan_add_copy_channels(y5_plan* p, const void* x, int x_ld, void* y, int y_ld, int64_t pixels, int c);
+int y5_plan_add_decode(y5_plan* p, const y5_decode_desc* d);
+int y5_plan_num_ops(const y5_plan* p);
+/* Replay all ops on `stream`. ext (host array of n_ext device pointers) supplies the external slots. */
+int y5_plan_run(y5_plan* p, void* const* ext, int n_ext, y5_stream_t stream);
+/* Replay with a hipEvent pair around every op; ms (host, n >= num_ops floats) receives per-op
+ * device time. Synchronises the stream. For measurement only. */
+int y5_plan_profile(y5_plan* p, void* const* ext, int n_ext, y5_stream_t stream, float* ms, int n);
+/* Kind (Y5_OP_*), algorithmic FLOPs and algorithmic bytes of op i (host-side bookkeeping). */
+#define Y5_OP_CONV 1
+#define Y5_OP_PACK 2
+#define Y5_OP_MAXPOOL 3
+#define Y5_OP_UPSAMPLE 4
+#define Y5_OP_COPY 5
+#define Y5_OP_DECODE 6
+int y5_plan_op_info(const y5_plan* p, int i, int* kind, double* flops, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* Y5HIP_H */

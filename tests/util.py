@@ -1,0 +1,115 @@
+"""Shared helpers of the test-suite: golden fixture loading, module construction from fixtures, BN calibration."""
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+CFG_DIR = os.path.join(ROOT, 'yolo_amd', 'models')
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
+
+
+def sd_of(z, strip=''):
+    """state_dict stored in a fixture under 'sd.<key>' (optionally without a leading prefix)."""
+    out = {}
+    for k in z.files:
+        if k.startswith('sd.'):
+            key = k[3:]
+            if strip and key.startswith(strip):
+                key = key[len(strip):]
+            out[key] = torch.from_numpy(z[k])
+    return out
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def build_model(cfg='yolov5s', seed=0, nc=None):
+    from yolo_amd.models.yolo import Model
+    torch.manual_seed(seed)
+    return quiet(Model, os.path.join(CFG_DIR, cfg + '.yaml'), 3, nc)
+
+
+def randomize_bn(module, seed):
+    """Same rule as tests/golden/make_golden.py: deterministic BatchNorm statistics by sorted state_dict key."""
+    g = torch.Generator().manual_seed(seed)
+    sd = module.state_dict()
+    with torch.no_grad():
+        for k in sorted(sd):
+            v = sd[k]
+            if k.endswith('running_mean'):
+                v.copy_(torch.randn(v.shape, generator=g) * 0.2)
+            elif k.endswith('running_var'):
+                v.copy_(torch.rand(v.shape, generator=g) * 1.5 + 0.5)
+            elif k.endswith('bn.weight'):
+                v.copy_(torch.rand(v.shape, generator=g) + 0.5)
+            elif k.endswith('bn.bias'):
+                v.copy_(torch.randn(v.shape, generator=g) * 0.2)
+
+
+def calibrate(model, seed=1, size=640, head_gain=2.0, batch=2):
+    """Synthetic-weight preparation used by the benchmarks: BatchNorm statistics from one train-mode pass on
+    uniform noise (momentum 1.0), then a gain on the Detect convs so that a realistic number of boxes passes a
+    0.001 confidence threshold."""
+    import torch.nn as nn
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(batch, 3, size, size, generator=g)
+    bns = [m for m in model.modules() if isinstance(m, nn.BatchNorm2d)]
+    old = [m.momentum for m in bns]
+    for m in bns:
+        m.momentum = 1.0
+    model.train()
+    with torch.no_grad():
+        model(x)
+    for m, mo in zip(bns, old):
+        m.momentum = mo
+    model.eval()
+    with torch.no_grad():
+        for conv in model.model[-1].m:
+            conv.weight.mul_(head_gain)
+    return model
+
+
+def block_from_fixture(name):
+    """(module, x, y) for a tests/golden/block_<name>.npz fixture, module in fp32 on the CPU."""
+    from yolo_amd.models import common
+    from yolo_amd.utils import torch_utils
+    z = golden('block_' + name)
+    sd = sd_of(z, 'model.0.')
+    ctor = {
+        'conv_k1s1': lambda: common.Conv(16, 24, 1, 1), 'conv_k3s1': lambda: common.Conv(16, 32, 3, 1),
+        'conv_k3s2': lambda: common.Conv(24, 40, 3, 2), 'conv_k3s2_fused': lambda: common.Conv(24, 40, 3, 2),
+        'conv_k3s1_odd': lambda: common.Conv(13, 25, 3, 1), 'focus': lambda: common.Focus(3, 32, 3),
+        'bottleneck_add': lambda: common.Bottleneck(32, 32, True, e=1.0),
+        'bottleneck_noadd': lambda: common.Bottleneck(32, 32, False, e=1.0),
+        'csp': lambda: common.BottleneckCSP(32, 32, n=2, shortcut=True),
+        'csp_noshortcut': lambda: common.BottleneckCSP(48, 32, n=1, shortcut=False),
+        'csp_fused': lambda: common.BottleneckCSP(32, 32, n=1, shortcut=True),
+        'spp': lambda: common.SPP(32, 32, (5, 9, 13)),
+    }[name]
+    m = ctor()
+    torch_utils.initialize_weights(m)
+    if name.endswith('_fused'):
+        for c in m.modules():
+            if type(c) is common.Conv:
+                c.conv = torch_utils.fuse_conv_and_bn(c.conv, c.bn)
+                c.bn = None
+                c.forward = c.fuseforward
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    return m, torch.from_numpy(z['x']), torch.from_numpy(z['y'])
+
+
+BLOCKS = ['conv_k1s1', 'conv_k3s1', 'conv_k3s2', 'conv_k3s2_fused', 'conv_k3s1_odd', 'focus', 'bottleneck_add',
+          'bottleneck_noadd', 'csp', 'csp_noshortcut', 'csp_fused', 'spp']

@@ -1,0 +1,320 @@
+// extern "C" surface of liby5hip.so: error reporting, single-op entry points and the launch plan.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "y5_common.h"
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+int y5_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" const char* y5_last_error(void) { return g_err; }
+extern "C" int y5_version(void) { return 100; }
+
+extern "C" int y5_device_arch(char* buf, int n) {
+    Y5_REQUIRE(buf && n > 0, "device_arch: bad buffer");
+    int dev = 0;
+    Y5_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    Y5_HIP(hipGetDeviceProperties(&prop, dev));
+    snprintf(buf, (size_t)n, "%s", prop.gcnArchName);
+    return Y5_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// single-op entry points
+// ------------------------------------------------------------------------------------------
+extern "C" int y5_conv_f16(const y5_conv_desc* d, y5_stream_t stream) {
+    Y5_REQUIRE(d, "conv: null descriptor");
+    return y5_launch_conv(*d, static_cast<hipStream_t>(stream));
+}
+extern "C" int y5_pack_image_f16(const void* x, void* y, int batch, int c, int h, int w, int focus, int y_ld,
+                                 y5_stream_t stream) {
+    return y5_launch_pack_image(x, y, batch, c, h, w, focus, y_ld, static_cast<hipStream_t>(stream));
+}
+extern "C" int y5_maxpool_f16(const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c, int k,
+                              y5_stream_t stream) {
+    return y5_launch_maxpool(x, x_ld, y, y_ld, batch, h, w, c, k, static_cast<hipStream_t>(stream));
+}
+extern "C" int y5_upsample2x_f16(const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c, int mode,
+                                 y5_stream_t stream) {
+    return y5_launch_upsample2x(x, x_ld, y, y_ld, batch, h, w, c, mode, static_cast<hipStream_t>(stream));
+}
+extern "C" int y5_copy_channels_f16(const void* x, int x_ld, void* y, int y_ld, int64_t pixels, int c,
+                                    y5_stream_t stream) {
+    return y5_launch_copy_channels(x, x_ld, y, y_ld, pixels, c, static_cast<hipStream_t>(stream));
+}
+extern "C" int y5_detect_decode_f16(const y5_decode_desc* d, y5_stream_t stream) {
+    Y5_REQUIRE(d, "decode: null descriptor");
+    return y5_launch_decode(*d, static_cast<hipStream_t>(stream));
+}
+
+// ------------------------------------------------------------------------------------------
+// launch plan
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct SlotRange {
+    const unsigned char* base = nullptr;
+    size_t bytes = 0;
+};
+
+struct PtrFix {  // pointer field of an op that must be rebased on an external slot at run time
+    int field;   // index into the op's pointer table
+    int slot;
+    size_t offset;
+};
+
+struct Op {
+    int kind = 0;
+    y5_conv_desc conv{};
+    y5_decode_desc dec{};
+    // generic pointwise arguments
+    const void* px = nullptr;
+    void* py = nullptr;
+    int i[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long pixels = 0;
+    std::vector<PtrFix> fixes;
+    double flops = 0.0, bytes = 0.0;
+};
+
+}  // namespace
+
+struct y5_plan {
+    std::vector<Op> ops;
+    SlotRange slots[16];
+};
+
+namespace {
+
+// If p lies inside a bound slot, remember to rebase it; returns false for a pointer straddling a slot end.
+void note_ptr(y5_plan* plan, Op& op, int field, const void* p) {
+    if (!p) return;
+    const unsigned char* c = static_cast<const unsigned char*>(p);
+    for (int s = 0; s < 16; ++s) {
+        const SlotRange& r = plan->slots[s];
+        if (r.base && c >= r.base && c < r.base + r.bytes) {
+            op.fixes.push_back({field, s, (size_t)(c - r.base)});
+            return;
+        }
+    }
+}
+
+bool set_ptr(Op& op, int field, const void* v) {
+    void* nv = const_cast<void*>(v);
+    switch (op.kind) {
+        case Y5_OP_CONV:
+            if (field == 0) op.conv.x = v;
+            else if (field == 1) op.conv.y = nv;
+            else if (field == 2) op.conv.res = v;
+            else return false;
+            return true;
+        case Y5_OP_DECODE:
+            if (field == 0) op.dec.head = v;
+            else if (field == 1) op.dec.x_out = nv;
+            else if (field == 2) op.dec.z_out = nv;
+            else return false;
+            return true;
+        default:
+            if (field == 0) op.px = v;
+            else if (field == 1) op.py = nv;
+            else return false;
+            return true;
+    }
+}
+
+int run_op(const Op& op, hipStream_t s) {
+    switch (op.kind) {
+        case Y5_OP_CONV: return y5_launch_conv(op.conv, s);
+        case Y5_OP_PACK: return y5_launch_pack_image(op.px, op.py, op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], s);
+        case Y5_OP_MAXPOOL: return y5_launch_maxpool(op.px, op.i[0], op.py, op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6], s);
+        case Y5_OP_UPSAMPLE: return y5_launch_upsample2x(op.px, op.i[0], op.py, op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6], s);
+        case Y5_OP_COPY: return y5_launch_copy_channels(op.px, op.i[0], op.py, op.i[1], op.pixels, op.i[2], s);
+        case Y5_OP_DECODE: return y5_launch_decode(op.dec, s);
+    }
+    return y5_fail(Y5_EINVAL, "plan: unknown op kind %d", op.kind);
+}
+
+// Returns the op with external pointers substituted.
+int resolve(const y5_plan* p, size_t idx, void* const* ext, int n_ext, Op& out) {
+    out = p->ops[idx];
+    for (const PtrFix& f : out.fixes) {
+        if (f.slot >= n_ext || !ext || !ext[f.slot])
+            return y5_fail(Y5_EINVAL, "plan: op %zu needs external slot %d but only %d were passed", idx, f.slot, n_ext);
+        if (!set_ptr(out, f.field, static_cast<const unsigned char*>(ext[f.slot]) + f.offset))
+            return y5_fail(Y5_EINVAL, "plan: op %zu has no pointer field %d", idx, f.field);
+    }
+    return Y5_OK;
+}
+
+template <typename F>
+int guarded(F&& f) {
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        return y5_fail(Y5_ENOMEM, "plan: host allocation failed");
+    } catch (...) {
+        return y5_fail(Y5_EINVAL, "plan: unexpected C++ exception");
+    }
+}
+
+}  // namespace
+
+extern "C" int y5_plan_create(y5_plan** out) {
+    Y5_REQUIRE(out, "plan_create: null output");
+    y5_plan* p = new (std::nothrow) y5_plan();
+    if (!p) return y5_fail(Y5_ENOMEM, "plan_create: host allocation failed");
+    *out = p;
+    return Y5_OK;
+}
+
+extern "C" void y5_plan_destroy(y5_plan* p) { delete p; }
+
+extern "C" int y5_plan_bind_slot(y5_plan* p, int slot, const void* base, size_t bytes) {
+    Y5_REQUIRE(p, "plan_bind_slot: null plan");
+    Y5_REQUIRE(slot >= 0 && slot < 16, "plan_bind_slot: slot %d out of range 0..15", slot);
+    Y5_REQUIRE(base && bytes > 0, "plan_bind_slot: empty range");
+    p->slots[slot].base = static_cast<const unsigned char*>(base);
+    p->slots[slot].bytes = bytes;
+    return Y5_OK;
+}
+
+extern "C" int y5_plan_add_conv(y5_plan* p, const y5_conv_desc* d) {
+    Y5_REQUIRE(p && d, "plan_add_conv: null argument");
+    return guarded([&]() {
+        Op op;
+        op.kind = Y5_OP_CONV;
+        op.conv = *d;
+        note_ptr(p, op, 0, d->x);
+        note_ptr(p, op, 1, d->y);
+        note_ptr(p, op, 2, d->res);
+        const double m = (double)d->batch * d->ho * d->wo;
+        op.flops = 2.0 * m * d->cout * d->ksize * d->ksize * d->cin;
+        op.bytes = 2.0 * ((double)d->batch * d->h * d->w_in * d->cin + m * d->cout * (d->res ? 2 : 1) +
+                          (double)d->cout * d->ksize * d->ksize * d->cin);
+        p->ops.push_back(op);
+        return Y5_OK;
+    });
+}
+
+static int add_pointwise(y5_plan* p, int kind, const void* x, void* y, const int* iv, int ni, long long pixels, double bytes) {
+    return guarded([&]() {
+        Op op;
+        op.kind = kind;
+        op.px = x;
+        op.py = y;
+        for (int k = 0; k < ni; ++k) op.i[k] = iv[k];
+        op.pixels = pixels;
+        op.bytes = bytes;
+        note_ptr(p, op, 0, x);
+        note_ptr(p, op, 1, y);
+        p->ops.push_back(op);
+        return Y5_OK;
+    });
+}
+
+extern "C" int y5_plan_add_pack_image(y5_plan* p, const void* x, void* y, int batch, int c, int h, int w, int focus, int y_ld) {
+    Y5_REQUIRE(p, "plan_add_pack_image: null plan");
+    const int iv[6] = {batch, c, h, w, focus, y_ld};
+    const double px = (double)batch * h * w;
+    return add_pointwise(p, Y5_OP_PACK, x, y, iv, 6, 0, 2.0 * px * c + 2.0 * (focus ? px / 4 : px) * y_ld);
+}
+
+extern "C" int y5_plan_add_maxpool(y5_plan* p, const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c, int k) {
+    Y5_REQUIRE(p, "plan_add_maxpool: null plan");
+    const int iv[7] = {x_ld, y_ld, batch, h, w, c, k};
+    return add_pointwise(p, Y5_OP_MAXPOOL, x, y, iv, 7, 0, 4.0 * batch * h * w * c);
+}
+
+extern "C" int y5_plan_add_upsample2x(y5_plan* p, const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c, int mode) {
+    Y5_REQUIRE(p, "plan_add_upsample2x: null plan");
+    const int iv[7] = {x_ld, y_ld, batch, h, w, c, mode};
+    return add_pointwise(p, Y5_OP_UPSAMPLE, x, y, iv, 7, 0, 10.0 * batch * h * w * c);
+}
+
+extern "C" int y5_plan_add_copy_channels(y5_plan* p, const void* x, int x_ld, void* y, int y_ld, int64_t pixels, int c) {
+    Y5_REQUIRE(p, "plan_add_copy_channels: null plan");
+    const int iv[3] = {x_ld, y_ld, c};
+    return add_pointwise(p, Y5_OP_COPY, x, y, iv, 3, pixels, 4.0 * (double)pixels * c);
+}
+
+extern "C" int y5_plan_add_decode(y5_plan* p, const y5_decode_desc* d) {
+    Y5_REQUIRE(p && d, "plan_add_decode: null argument");
+    return guarded([&]() {
+        Op op;
+        op.kind = Y5_OP_DECODE;
+        op.dec = *d;
+        note_ptr(p, op, 0, d->head);
+        note_ptr(p, op, 1, d->x_out);
+        note_ptr(p, op, 2, d->z_out);
+        // algorithmic bytes: read the head values once, write z once (fp16)
+        op.bytes = 4.0 * d->batch * d->ny * d->nx * d->na * d->no;
+        p->ops.push_back(op);
+        return Y5_OK;
+    });
+}
+
+extern "C" int y5_plan_num_ops(const y5_plan* p) { return p ? (int)p->ops.size() : 0; }
+
+extern "C" int y5_plan_op_info(const y5_plan* p, int i, int* kind, double* flops, double* bytes) {
+    Y5_REQUIRE(p && i >= 0 && i < (int)p->ops.size(), "plan_op_info: index %d out of range", i);
+    if (kind) *kind = p->ops[(size_t)i].kind;
+    if (flops) *flops = p->ops[(size_t)i].flops;
+    if (bytes) *bytes = p->ops[(size_t)i].bytes;
+    return Y5_OK;
+}
+
+extern "C" int y5_plan_run(y5_plan* p, void* const* ext, int n_ext, y5_stream_t stream) {
+    Y5_REQUIRE(p, "plan_run: null plan");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return guarded([&]() {
+        Op op;
+        for (size_t k = 0; k < p->ops.size(); ++k) {
+            const Op* cur = &p->ops[k];
+            if (!cur->fixes.empty()) {
+                if (int rc = resolve(p, k, ext, n_ext, op)) return rc;
+                cur = &op;
+            }
+            if (int rc = run_op(*cur, s)) return rc;
+        }
+        return (int)Y5_OK;
+    });
+}
+
+extern "C" int y5_plan_profile(y5_plan* p, void* const* ext, int n_ext, y5_stream_t stream, float* ms, int n) {
+    Y5_REQUIRE(p && ms, "plan_profile: null argument");
+    Y5_REQUIRE(n >= (int)p->ops.size(), "plan_profile: ms holds %d entries, plan has %zu ops", n, p->ops.size());
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return guarded([&]() {
+        const size_t nops = p->ops.size();
+        std::vector<hipEvent_t> ev(nops + 1, nullptr);
+        int rc = Y5_OK;
+        for (size_t k = 0; k <= nops && rc == Y5_OK; ++k)
+            if (hipEventCreate(&ev[k]) != hipSuccess) rc = y5_fail(Y5_EHIP, "plan_profile: hipEventCreate failed");
+        Op op;
+        if (rc == Y5_OK && hipEventRecord(ev[0], s) != hipSuccess) rc = y5_fail(Y5_EHIP, "plan_profile: hipEventRecord failed");
+        for (size_t k = 0; k < nops && rc == Y5_OK; ++k) {
+            rc = resolve(p, k, ext, n_ext, op);
+            if (rc == Y5_OK) rc = run_op(op, s);
+            if (rc == Y5_OK && hipEventRecord(ev[k + 1], s) != hipSuccess) rc = y5_fail(Y5_EHIP, "plan_profile: hipEventRecord failed");
+        }
+        if (rc == Y5_OK && hipStreamSynchronize(s) != hipSuccess) rc = y5_fail(Y5_EHIP, "plan_profile: hipStreamSynchronize failed");
+        for (size_t k = 0; k < nops && rc == Y5_OK; ++k)
+            if (hipEventElapsedTime(&ms[k], ev[k], ev[k + 1]) != hipSuccess) rc = y5_fail(Y5_EHIP, "plan_profile: hipEventElapsedTime failed");
+        for (hipEvent_t e : ev)
+            if (e) (void)hipEventDestroy(e);
+        return rc;
+    });
+}

@@ -1,0 +1,421 @@
+// Batched non-maximum suppression for gfx950, three kernels per call and no host round trip:
+//   1. candidates: confidence filter + multi-label expansion with wavefront-ballot compaction.
+//      Every surviving (anchor row, class) pair becomes one 64-bit sort key
+//      [descending-score bits | anchor_row*nc + class]; the slot order in the key buffer is
+//      irrelevant because the key itself carries the reference's tie order (lower index first).
+//   2. sort: one 1024-thread workgroup per image runs a bitonic sort of its keys in LDS
+//      (blocks of 16384 keys; larger sets take extra passes through global memory).
+//   3. select: one workgroup per image walks the sorted candidates 64 at a time.  The kept boxes
+//      live in LDS; 16 waves test the chunk against disjoint parts of the kept list and publish
+//      64-bit suppression masks, then wave 0 resolves the chunk greedily with ballots.  Selection
+//      stops at max_det kept boxes, which is all the reference returns.
+// All IoU arithmetic is IEEE fp32 with the operation order of torchvision's CPU kernel
+// (this file is compiled with -ffp-contract=off) and compared in double.
+#include "y5_common.h"
+
+namespace {
+
+constexpr int SORT_THREADS = 1024;
+constexpr int SORT_LDS_KEYS = 16384;  // 128 KiB of keys per LDS block
+constexpr int SEL_THREADS = 1024;
+constexpr int SEL_WAVES = SEL_THREADS / 64;
+constexpr int MAX_DET_CAP = 1024;
+constexpr float CLASS_OFFSET = 4096.f;  // max_wh of the reference
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ unsigned score_desc_bits(float s) {
+    // order-preserving map float -> uint, then inverted so that ascending keys = descending scores
+    const unsigned u = __float_as_uint(s);
+    const unsigned mono = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ~mono;
+}
+__device__ __forceinline__ float score_from_bits(unsigned inv) {
+    const unsigned mono = ~inv;
+    const unsigned u = (mono & 0x80000000u) ? (mono & 0x7fffffffu) : ~mono;
+    return __uint_as_float(u);
+}
+
+__device__ __forceinline__ float ldf(const f16* p) { return (float)*p; }
+__device__ __forceinline__ float ldf(const float* p) { return *p; }
+
+// ------------------------------------------------------------------------------------------
+// 1. candidates
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void nms_candidates_kernel(const T* __restrict__ pred, int n_rows, int no, float conf_thres,
+                                                             const uint8_t* __restrict__ class_keep, u64* __restrict__ keys,
+                                                             int cap, int* __restrict__ counters) {
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nc = no - 5;
+    const int row_base = (blockIdx.x * 4 + wave) * 64;
+    if (row_base >= n_rows) return;
+    const int row = row_base + lane;
+    const T* img = pred + (long long)b * n_rows * no;
+    float obj = 0.f;
+    bool pass = false;
+    if (row < n_rows) {
+        obj = ldf(img + (long long)row * no + 4);
+        pass = obj > conf_thres;
+    }
+    u64 rows_mask = __ballot(pass);
+    u64* out = keys + (long long)b * cap;
+    while (rows_mask) {
+        const int src = __builtin_ctzll(rows_mask);
+        rows_mask &= rows_mask - 1;
+        const int r = row_base + src;
+        const float obj_r = __shfl(obj, src);
+        const T* rowp = img + (long long)r * no + 5;
+        for (int c0 = 0; c0 < nc; c0 += 64) {
+            const int c = c0 + lane;
+            bool ok = false;
+            float conf = 0.f;
+            if (c < nc) {
+                conf = ldf(rowp + c) * obj_r;  // conf = cls * obj in fp32
+                ok = conf > conf_thres && (!class_keep || class_keep[c]);
+            }
+            const u64 m = __ballot(ok);
+            if (m) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&counters[b], __builtin_popcountll(m));
+                base = __shfl(base, 0);
+                const int pos = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                if (ok && pos < cap) out[pos] = ((u64)score_desc_bits(conf) << 32) | (unsigned)(r * nc + c);
+            }
+        }
+    }
+}
+
+// keys for the plain box-set entry point: one candidate per box
+__global__ __launch_bounds__(256) void nms_box_keys_kernel(const float* __restrict__ scores, int n, u64* __restrict__ keys,
+                                                           int* __restrict__ counter) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) keys[i] = ((u64)score_desc_bits(scores[i]) << 32) | (unsigned)i;
+    if (i == 0) counter[0] = n;
+}
+
+// ------------------------------------------------------------------------------------------
+// 2. sort (ascending 64-bit keys), one workgroup per image
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cmpxchg(u64& a, u64& b, bool up) {
+    if ((a > b) == up) { const u64 t = a; a = b; b = t; }
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void nms_sort_kernel(u64* __restrict__ keys_all, int cap_pow2, int cap,
+                                                                const int* __restrict__ counters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u64* s = reinterpret_cast<u64*>(smem_raw);
+    const int b = blockIdx.x;
+    u64* keys = keys_all + (long long)b * cap_pow2;
+    int n = counters[b];
+    if (n > cap) n = cap;
+    if (n <= 1) return;
+    int P = 64;
+    while (P < n) P <<= 1;
+    const int tid = threadIdx.x;
+
+    if (P <= SORT_LDS_KEYS) {
+        for (int i = tid; i < P; i += SORT_THREADS) s[i] = i < n ? keys[i] : ~0ull;
+        __syncthreads();
+        for (int k = 2; k <= P; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < (P >> 1); t += SORT_THREADS) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    cmpxchg(s[i], s[i | j], (i & k) == 0);
+                }
+                __syncthreads();
+            }
+        }
+        for (int i = tid; i < n; i += SORT_THREADS) keys[i] = s[i];
+        return;
+    }
+
+    // large sets: pad in global memory, sort LDS-sized blocks, then merge stages whose partner
+    // distance spans blocks through global memory
+    for (int i = n + tid; i < P; i += SORT_THREADS) keys[i] = ~0ull;
+    __syncthreads();
+    const int nblk = P / SORT_LDS_KEYS;
+    for (int blk = 0; blk < nblk; ++blk) {
+        u64* g = keys + (long long)blk * SORT_LDS_KEYS;
+        const int gbase = blk * SORT_LDS_KEYS;
+        for (int i = tid; i < SORT_LDS_KEYS; i += SORT_THREADS) s[i] = g[i];
+        __syncthreads();
+        for (int k = 2; k <= SORT_LDS_KEYS; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < (SORT_LDS_KEYS >> 1); t += SORT_THREADS) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    cmpxchg(s[i], s[i | j], ((gbase + i) & k) == 0);
+                }
+                __syncthreads();
+            }
+        }
+        for (int i = tid; i < SORT_LDS_KEYS; i += SORT_THREADS) g[i] = s[i];
+        __syncthreads();
+    }
+    for (int k = 2 * SORT_LDS_KEYS; k <= P; k <<= 1) {
+        for (int j = k >> 1; j >= SORT_LDS_KEYS; j >>= 1) {
+            for (int t = tid; t < (P >> 1); t += SORT_THREADS) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                u64 x = keys[i], y = keys[i | j];
+                if ((x > y) == ((i & k) == 0)) { keys[i] = y; keys[i | j] = x; }
+            }
+            __syncthreads();
+        }
+        for (int blk = 0; blk < nblk; ++blk) {
+            u64* g = keys + (long long)blk * SORT_LDS_KEYS;
+            const int gbase = blk * SORT_LDS_KEYS;
+            for (int i = tid; i < SORT_LDS_KEYS; i += SORT_THREADS) s[i] = g[i];
+            __syncthreads();
+            for (int j = SORT_LDS_KEYS >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < (SORT_LDS_KEYS >> 1); t += SORT_THREADS) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    cmpxchg(s[i], s[i | j], ((gbase + i) & k) == 0);
+                }
+                __syncthreads();
+            }
+            for (int i = tid; i < SORT_LDS_KEYS; i += SORT_THREADS) g[i] = s[i];
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// 3. greedy selection
+// ------------------------------------------------------------------------------------------
+struct Box { float x1, y1, x2, y2; };
+
+// suppress(j by kept i)  <=>  (double)(inter / (area_i + area_j - inter)) > thr, torchvision CPU order
+__device__ __forceinline__ bool suppresses(const Box& k, float karea, const Box& c, float carea, double thr) {
+    const float xx1 = fmaxf(k.x1, c.x1), yy1 = fmaxf(k.y1, c.y1);
+    const float xx2 = fminf(k.x2, c.x2), yy2 = fminf(k.y2, c.y2);
+    const float w = fmaxf(0.f, __fsub_rn(xx2, xx1)), h = fmaxf(0.f, __fsub_rn(yy2, yy1));
+    const float inter = __fmul_rn(w, h);
+    const float ovr = __fdiv_rn(inter, __fsub_rn(__fadd_rn(karea, carea), inter));
+    return (double)ovr > thr;
+}
+
+struct SelectArgs {
+    const void* pred;      // prediction rows (pred mode) or boxes (n,4) fp32 (box mode)
+    const u64* keys;       // sorted keys, cap_pow2 per image
+    const int* counters;
+    float* det;            // pred mode outputs
+    int* count;
+    int* kept_index;
+    int* n_candidates;
+    long long* keep64;     // box mode output
+    double iou_thres;
+    int n_rows, no, cap, cap_pow2, max_det, agnostic;
+};
+
+template <typename T, bool BOXES>
+__global__ __launch_bounds__(SEL_THREADS) void nms_select_kernel(const SelectArgs a) {
+    __shared__ Box kbox[MAX_DET_CAP];
+    __shared__ float karea[MAX_DET_CAP];
+    __shared__ u64 sup[SEL_WAVES];
+    __shared__ int kcount;
+
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nc = a.no - 5;
+    const int total = a.counters[b];
+    const int n = total < a.cap ? total : a.cap;
+    const u64* keys = a.keys + (long long)b * a.cap_pow2;
+    if (threadIdx.x == 0) {
+        kcount = 0;
+        if (a.n_candidates) a.n_candidates[b] = total;
+    }
+    __syncthreads();
+
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int K = kcount;  // stable between the barriers below
+        if (K >= a.max_det) break;
+        // every wave materialises the same 64 candidates
+        const int ci = c0 + lane;
+        const bool valid = ci < n;
+        Box cb = {0.f, 0.f, 0.f, 0.f};   // box used for IoU (class-offset in pred mode)
+        Box ob = cb;                      // box reported
+        float score = 0.f, cls = 0.f;
+        unsigned flat = 0;
+        if (valid) {
+            const u64 key = keys[ci];
+            flat = (unsigned)key;
+            score = score_from_bits((unsigned)(key >> 32));
+            if (BOXES) {
+                const float4 v = reinterpret_cast<const float4*>(a.pred)[flat];
+                cb = {v.x, v.y, v.z, v.w};
+                ob = cb;
+            } else {
+                const unsigned row = flat / (unsigned)nc;
+                const unsigned c = flat - row * (unsigned)nc;
+                const T* p = static_cast<const T*>(a.pred) + ((long long)b * a.n_rows + row) * a.no;
+                const float cx = ldf(p), cy = ldf(p + 1), bw = ldf(p + 2), bh = ldf(p + 3);
+                const float hw = bw / 2.f, hh = bh / 2.f;
+                ob = {__fsub_rn(cx, hw), __fsub_rn(cy, hh), __fadd_rn(cx, hw), __fadd_rn(cy, hh)};
+                cls = (float)c;
+                const float off = a.agnostic ? 0.f : __fmul_rn(cls, CLASS_OFFSET);
+                cb = {__fadd_rn(ob.x1, off), __fadd_rn(ob.y1, off), __fadd_rn(ob.x2, off), __fadd_rn(ob.y2, off)};
+            }
+        }
+        const float carea = __fmul_rn(__fsub_rn(cb.x2, cb.x1), __fsub_rn(cb.y2, cb.y1));
+
+        // kept-list test, kept entries strided over the waves
+        bool dead = false;
+        for (int k = wave; k < K; k += SEL_WAVES) {
+            const Box kb = kbox[k];
+            if (!dead && suppresses(kb, karea[k], cb, carea, a.iou_thres)) dead = true;
+        }
+        const u64 m = __ballot(dead);
+        if (lane == 0) sup[wave] = m;
+        __syncthreads();
+
+        if (wave == 0) {
+            u64 all = 0;
+#pragma unroll
+            for (int w = 0; w < SEL_WAVES; ++w) all |= sup[w];
+            u64 alive = __ballot(valid) & ~all;
+            int kk = K;
+            while (alive && kk < a.max_det) {
+                const int i = __builtin_ctzll(alive);
+                alive &= alive - 1;
+                Box ib;
+                ib.x1 = __shfl(cb.x1, i); ib.y1 = __shfl(cb.y1, i); ib.x2 = __shfl(cb.x2, i); ib.y2 = __shfl(cb.y2, i);
+                const float iarea = __shfl(carea, i);
+                if (lane == i) {
+                    kbox[kk] = cb;
+                    karea[kk] = carea;
+                    if (BOXES) {
+                        a.keep64[kk] = (long long)flat;
+                    } else {
+                        float* d = a.det + ((long long)b * a.max_det + kk) * 6;
+                        d[0] = ob.x1; d[1] = ob.y1; d[2] = ob.x2; d[3] = ob.y2; d[4] = score; d[5] = cls;
+                        if (a.kept_index) a.kept_index[(long long)b * a.max_det + kk] = (int)flat;
+                    }
+                }
+                ++kk;
+                const bool s = lane > i && suppresses(ib, iarea, cb, carea, a.iou_thres);
+                alive &= ~__ballot(s);
+            }
+            if (lane == 0) kcount = kk;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.count[b] = kcount;
+}
+
+// zero the unused tail of det rows so that padded outputs are deterministic
+__global__ __launch_bounds__(256) void nms_clear_tail_kernel(float* det, int* kept_index, const int* count, int max_det) {
+    const int b = blockIdx.x;
+    const int c = count[b];
+    for (int i = c * 6 + threadIdx.x; i < max_det * 6; i += 256) det[(long long)b * max_det * 6 + i] = 0.f;
+    if (kept_index)
+        for (int i = c + threadIdx.x; i < max_det; i += 256) kept_index[(long long)b * max_det + i] = -1;
+}
+
+int pow2_at_least(int v) {
+    int p = 64;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+int ensure_sort_lds() {
+    static bool done = false;  // per process; the attribute is per function and idempotent
+    if (!done) {
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   SORT_LDS_KEYS * (int)sizeof(u64)));
+        done = true;
+    }
+    return Y5_OK;
+}
+
+}  // namespace
+
+extern "C" size_t y5_nms_workspace_bytes(int batch, int max_candidates) {
+    if (batch <= 0 || max_candidates <= 0) return 0;
+    const size_t counters = ((size_t)batch * sizeof(int) + 255) / 256 * 256;
+    return counters + (size_t)batch * pow2_at_least(max_candidates) * sizeof(u64);
+}
+
+extern "C" int y5_nms_batched(const y5_nms_desc* d, y5_stream_t stream) {
+    Y5_REQUIRE(d, "nms: null descriptor");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Y5_REQUIRE(d->pred && d->workspace && d->det && d->count, "nms: null pointer");
+    Y5_REQUIRE(d->pred_dtype == 0 || d->pred_dtype == 1, "nms: pred_dtype %d not in {0 fp16, 1 fp32}", d->pred_dtype);
+    Y5_REQUIRE(d->batch > 0 && d->n_rows > 0 && d->no >= 6, "nms: bad shape (%d, %d, %d)", d->batch, d->n_rows, d->no);
+    Y5_REQUIRE((long long)d->n_rows * (d->no - 5) < 0x7fffffffLL, "nms: rows*classes overflows the 32-bit candidate index");
+    Y5_REQUIRE(d->max_det > 0 && d->max_det <= MAX_DET_CAP, "nms: max_det %d out of range 1..%d", d->max_det, MAX_DET_CAP);
+    Y5_REQUIRE(d->max_candidates > 0, "nms: max_candidates must be positive");
+    Y5_REQUIRE(d->conf_thres >= 0.f, "nms: conf_thres must be >= 0");
+    const size_t need = y5_nms_workspace_bytes(d->batch, d->max_candidates);
+    if (d->workspace_bytes < need) return y5_fail(Y5_EWORKSPACE, "nms: workspace %zu < %zu bytes", d->workspace_bytes, need);
+    Y5_REQUIRE(y5_aligned16(d->workspace), "nms: workspace must be 16-byte aligned");
+    if (int rc = ensure_sort_lds()) return rc;
+
+    const size_t counters_bytes = ((size_t)d->batch * sizeof(int) + 255) / 256 * 256;
+    int* counters = static_cast<int*>(d->workspace);
+    u64* keys = reinterpret_cast<u64*>(static_cast<unsigned char*>(d->workspace) + counters_bytes);
+    const int cap_pow2 = pow2_at_least(d->max_candidates);
+
+    Y5_HIP(hipMemsetAsync(counters, 0, counters_bytes, s));
+    const dim3 cgrid((unsigned)((d->n_rows + 255) / 256), (unsigned)d->batch);
+    if (d->pred_dtype == 0)
+        hipLaunchKernelGGL(nms_candidates_kernel<f16>, cgrid, dim3(256), 0, s, static_cast<const f16*>(d->pred), d->n_rows, d->no,
+                           d->conf_thres, d->class_keep, keys, cap_pow2, counters);
+    else
+        hipLaunchKernelGGL(nms_candidates_kernel<float>, cgrid, dim3(256), 0, s, static_cast<const float*>(d->pred), d->n_rows,
+                           d->no, d->conf_thres, d->class_keep, keys, cap_pow2, counters);
+    Y5_LAUNCH_CHECK("nms_candidates_kernel");
+
+    hipLaunchKernelGGL(nms_sort_kernel, dim3((unsigned)d->batch), dim3(SORT_THREADS), SORT_LDS_KEYS * sizeof(u64), s, keys, cap_pow2,
+                       d->max_candidates, counters);
+    Y5_LAUNCH_CHECK("nms_sort_kernel");
+
+    SelectArgs a;
+    a.pred = d->pred; a.keys = keys; a.counters = counters;
+    a.det = d->det; a.count = d->count; a.kept_index = d->kept_index; a.n_candidates = d->n_candidates; a.keep64 = nullptr;
+    a.iou_thres = d->iou_thres;
+    a.n_rows = d->n_rows; a.no = d->no; a.cap = d->max_candidates; a.cap_pow2 = cap_pow2; a.max_det = d->max_det; a.agnostic = d->agnostic;
+    if (d->pred_dtype == 0)
+        hipLaunchKernelGGL((nms_select_kernel<f16, false>), dim3((unsigned)d->batch), dim3(SEL_THREADS), 0, s, a);
+    else
+        hipLaunchKernelGGL((nms_select_kernel<float, false>), dim3((unsigned)d->batch), dim3(SEL_THREADS), 0, s, a);
+    Y5_LAUNCH_CHECK("nms_select_kernel");
+    hipLaunchKernelGGL(nms_clear_tail_kernel, dim3((unsigned)d->batch), dim3(256), 0, s, d->det, d->kept_index, d->count, d->max_det);
+    Y5_LAUNCH_CHECK("nms_clear_tail_kernel");
+    return Y5_OK;
+}
+
+extern "C" int y5_nms_boxes_f32(const float* boxes, const float* scores, int n, double iou_thres, int64_t* keep,
+                                int32_t* keep_count, int max_keep, void* workspace, size_t workspace_bytes,
+                                y5_stream_t stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Y5_REQUIRE(keep_count && workspace, "nms_boxes: null pointer");
+    Y5_REQUIRE(n >= 0, "nms_boxes: negative n");
+    Y5_REQUIRE(max_keep > 0 && max_keep <= MAX_DET_CAP, "nms_boxes: max_keep %d out of range 1..%d", max_keep, MAX_DET_CAP);
+    if (n == 0) {
+        Y5_HIP(hipMemsetAsync(keep_count, 0, sizeof(int32_t), s));
+        return Y5_OK;
+    }
+    Y5_REQUIRE(boxes && scores && keep, "nms_boxes: null pointer");
+    Y5_REQUIRE(y5_aligned16(boxes) && y5_aligned16(workspace), "nms_boxes: boxes/workspace must be 16-byte aligned");
+    const size_t need = y5_nms_workspace_bytes(1, n);
+    if (workspace_bytes < need) return y5_fail(Y5_EWORKSPACE, "nms_boxes: workspace %zu < %zu bytes", workspace_bytes, need);
+    if (int rc = ensure_sort_lds()) return rc;
+    int* counters = static_cast<int*>(workspace);
+    u64* keys = reinterpret_cast<u64*>(static_cast<unsigned char*>(workspace) + 256);
+    const int cap_pow2 = pow2_at_least(n);
+    hipLaunchKernelGGL(nms_box_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scores, n, keys, counters);
+    Y5_LAUNCH_CHECK("nms_box_keys_kernel");
+    hipLaunchKernelGGL(nms_sort_kernel, dim3(1), dim3(SORT_THREADS), SORT_LDS_KEYS * sizeof(u64), s, keys, cap_pow2, n, counters);
+    Y5_LAUNCH_CHECK("nms_sort_kernel");
+    SelectArgs a;
+    a.pred = boxes; a.keys = keys; a.counters = counters;
+    a.det = nullptr; a.count = keep_count; a.kept_index = nullptr; a.n_candidates = nullptr; a.keep64 = reinterpret_cast<long long*>(keep);
+    a.iou_thres = iou_thres;
+    a.n_rows = n; a.no = 6; a.cap = n; a.cap_pow2 = cap_pow2; a.max_det = max_keep; a.agnostic = 1;
+    hipLaunchKernelGGL((nms_select_kernel<float, true>), dim3(1), dim3(SEL_THREADS), 0, s, a);
+    Y5_LAUNCH_CHECK("nms_select_kernel");
+    return Y5_OK;
+}

@@ -1,0 +1,178 @@
+// HBM-bound data-movement kernels of the conv forward: image packing (with the Focus gather),
+// stride-1 max pooling for SPP, 2x upsampling into a concat slice, and pitched channel copies.
+// All of them move 16-byte channel vectors (8 fp16) per lane so that a wave touches 1 KiB per
+// instruction, and grid-stride over a capped grid.
+#include "y5_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+inline unsigned grid_for(long long work_items) {
+    long long blocks = (work_items + kThreads - 1) / kThreads;
+    const long long cap = 256LL * 16;  // 256 CUs x 16 resident workgroups is plenty for streaming
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+// One thread per output pixel; writes y_ld/8 vectors.  focus: out channel q*C + c reads
+// x[b, c, 2*oy + (q&1), 2*ox + (q>>1)]  (q = 0..3 -> (row,col) parity (0,0),(1,0),(0,1),(1,1)).
+__global__ __launch_bounds__(kThreads) void pack_image_kernel(const f16* __restrict__ x, f16* __restrict__ y, int batch,
+                                                              int C, int H, int W, int focus, int y_ld) {
+    const int Ho = focus ? H / 2 : H, Wo = focus ? W / 2 : W;
+    const long long total = (long long)batch * Ho * Wo;
+    const int cvalid = focus ? 4 * C : C;
+    for (long long p = (long long)blockIdx.x * kThreads + threadIdx.x; p < total; p += (long long)gridDim.x * kThreads) {
+        const int ox = (int)(p % Wo);
+        const long long t = p / Wo;
+        const int oy = (int)(t % Ho);
+        const long long b = t / Ho;
+        const f16* xb = x + b * (long long)C * H * W;
+        f16* yp = y + p * y_ld;
+        for (int c0 = 0; c0 < y_ld; c0 += 8) {
+            f16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ch = c0 + e;
+                f16 val = (f16)0.f;
+                if (ch < cvalid) {
+                    if (focus) {
+                        const int q = ch / C, c = ch - q * C;
+                        val = xb[((long long)c * H + (2 * oy + (q & 1))) * W + 2 * ox + (q >> 1)];
+                    } else {
+                        val = xb[((long long)ch * H + oy) * W + ox];
+                    }
+                }
+                v[e] = val;
+            }
+            *reinterpret_cast<f16x8*>(yp + c0) = v;
+        }
+    }
+}
+
+// One thread per (pixel, 8-channel vector).
+__global__ __launch_bounds__(kThreads) void maxpool_kernel(const f16* __restrict__ x, int x_ld, f16* __restrict__ y, int y_ld,
+                                                           int batch, int H, int W, int C8, int k) {
+    const long long total = (long long)batch * H * W * C8;
+    const int r = k / 2;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long long)gridDim.x * kThreads) {
+        const int c8 = (int)(i % C8);
+        const long long p = i / C8;
+        const int px = (int)(p % W);
+        const long long t = p / W;
+        const int py = (int)(t % H);
+        const long long b = t / H;
+        f16x8 m;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = (f16)(-__builtin_inff());
+        const int y0 = py - r < 0 ? 0 : py - r, y1 = py + r >= H ? H - 1 : py + r;
+        const int x0 = px - r < 0 ? 0 : px - r, x1 = px + r >= W ? W - 1 : px + r;
+        for (int yy = y0; yy <= y1; ++yy) {
+            const f16* row = x + ((b * H + yy) * (long long)W) * x_ld + c8 * 8;
+            for (int xx = x0; xx <= x1; ++xx) {
+                const f16x8 v = *reinterpret_cast<const f16x8*>(row + (long long)xx * x_ld);
+                m = __builtin_elementwise_max(m, v);
+            }
+        }
+        *reinterpret_cast<f16x8*>(y + p * y_ld + c8 * 8) = m;
+    }
+}
+
+// One thread per (output pixel, 8-channel vector).  Bilinear follows ATen's align_corners=False
+// rule: src = max(0, 0.5*(dst + 0.5) - 0.5), i1 = min(i0 + 1, in - 1), fp32 blend, one rounding.
+__global__ __launch_bounds__(kThreads) void upsample2x_kernel(const f16* __restrict__ x, int x_ld, f16* __restrict__ y, int y_ld,
+                                                              int batch, int H, int W, int C8, int mode) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const long long total = (long long)batch * Ho * Wo * C8;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long long)gridDim.x * kThreads) {
+        const int c8 = (int)(i % C8);
+        const long long p = i / C8;
+        const int ox = (int)(p % Wo);
+        const long long t = p / Wo;
+        const int oy = (int)(t % Ho);
+        const long long b = t / Ho;
+        const f16* xb = x + (b * H * (long long)W) * x_ld + c8 * 8;
+        f16x8 out;
+        if (mode == 0) {
+            out = *reinterpret_cast<const f16x8*>(xb + ((long long)(oy >> 1) * W + (ox >> 1)) * x_ld);
+        } else {
+            float sy = 0.5f * (oy + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
+            float sx = 0.5f * (ox + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
+            const int iy0 = (int)sy, ix0 = (int)sx;
+            const int iy1 = iy0 + (iy0 < H - 1 ? 1 : 0), ix1 = ix0 + (ix0 < W - 1 ? 1 : 0);
+            const float ly1 = sy - iy0, lx1 = sx - ix0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+            const f16x8 v00 = *reinterpret_cast<const f16x8*>(xb + ((long long)iy0 * W + ix0) * x_ld);
+            const f16x8 v01 = *reinterpret_cast<const f16x8*>(xb + ((long long)iy0 * W + ix1) * x_ld);
+            const f16x8 v10 = *reinterpret_cast<const f16x8*>(xb + ((long long)iy1 * W + ix0) * x_ld);
+            const f16x8 v11 = *reinterpret_cast<const f16x8*>(xb + ((long long)iy1 * W + ix1) * x_ld);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                out[e] = (f16)(ly0 * (lx0 * (float)v00[e] + lx1 * (float)v01[e]) + ly1 * (lx0 * (float)v10[e] + lx1 * (float)v11[e]));
+        }
+        *reinterpret_cast<f16x8*>(y + p * y_ld + c8 * 8) = out;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void copy_channels_kernel(const f16* __restrict__ x, int x_ld, f16* __restrict__ y, int y_ld,
+                                                                 long long pixels, int C8) {
+    const long long total = pixels * C8;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long long)gridDim.x * kThreads) {
+        const int c8 = (int)(i % C8);
+        const long long p = i / C8;
+        *reinterpret_cast<f16x8*>(y + p * y_ld + c8 * 8) = *reinterpret_cast<const f16x8*>(x + p * x_ld + c8 * 8);
+    }
+}
+
+}  // namespace
+
+int y5_launch_pack_image(const void* x, void* y, int batch, int c, int h, int w, int focus, int y_ld, hipStream_t s) {
+    Y5_REQUIRE(x && y, "pack_image: null pointer");
+    Y5_REQUIRE(batch > 0 && c > 0 && h > 0 && w > 0, "pack_image: empty tensor");
+    Y5_REQUIRE(!focus || (h % 2 == 0 && w % 2 == 0), "pack_image: focus needs even h,w (got %dx%d)", h, w);
+    Y5_REQUIRE(y_ld % 8 == 0 && y_ld >= (focus ? 4 * c : c), "pack_image: y_ld %d too small or not a multiple of 8", y_ld);
+    Y5_REQUIRE(y5_aligned16(y), "pack_image: output must be 16-byte aligned");
+    const long long total = (long long)batch * (focus ? h / 2 : h) * (focus ? w / 2 : w);
+    hipLaunchKernelGGL(pack_image_kernel, dim3(grid_for(total)), dim3(kThreads), 0, s, static_cast<const f16*>(x),
+                       static_cast<f16*>(y), batch, c, h, w, focus, y_ld);
+    Y5_LAUNCH_CHECK("pack_image_kernel");
+    return Y5_OK;
+}
+
+int y5_launch_maxpool(const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c, int k, hipStream_t s) {
+    Y5_REQUIRE(x && y, "maxpool: null pointer");
+    Y5_REQUIRE(k % 2 == 1 && k >= 1 && k <= 13, "maxpool: k %d must be odd and <= 13", k);
+    Y5_REQUIRE(c > 0 && c % 8 == 0 && x_ld % 8 == 0 && y_ld % 8 == 0 && x_ld >= c && y_ld >= c, "maxpool: channels/pitches must be multiples of 8");
+    Y5_REQUIRE(batch > 0 && h > 0 && w > 0, "maxpool: empty tensor");
+    Y5_REQUIRE(y5_aligned16(x) && y5_aligned16(y), "maxpool: pointers must be 16-byte aligned");
+    const long long total = (long long)batch * h * w * (c / 8);
+    hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total)), dim3(kThreads), 0, s, static_cast<const f16*>(x), x_ld,
+                       static_cast<f16*>(y), y_ld, batch, h, w, c / 8, k);
+    Y5_LAUNCH_CHECK("maxpool_kernel");
+    return Y5_OK;
+}
+
+int y5_launch_upsample2x(const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c, int mode,
+                         hipStream_t s) {
+    Y5_REQUIRE(x && y, "upsample2x: null pointer");
+    Y5_REQUIRE(mode == 0 || mode == 1, "upsample2x: mode %d not in {0 nearest, 1 bilinear}", mode);
+    Y5_REQUIRE(c > 0 && c % 8 == 0 && x_ld % 8 == 0 && y_ld % 8 == 0 && x_ld >= c && y_ld >= c, "upsample2x: channels/pitches must be multiples of 8");
+    Y5_REQUIRE(batch > 0 && h > 0 && w > 0, "upsample2x: empty tensor");
+    Y5_REQUIRE(y5_aligned16(x) && y5_aligned16(y), "upsample2x: pointers must be 16-byte aligned");
+    const long long total = (long long)batch * 4 * h * w * (c / 8);
+    hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for(total)), dim3(kThreads), 0, s, static_cast<const f16*>(x), x_ld,
+                       static_cast<f16*>(y), y_ld, batch, h, w, c / 8, mode);
+    Y5_LAUNCH_CHECK("upsample2x_kernel");
+    return Y5_OK;
+}
+
+int y5_launch_copy_channels(const void* x, int x_ld, void* y, int y_ld, int64_t pixels, int c, hipStream_t s) {
+    Y5_REQUIRE(x && y, "copy_channels: null pointer");
+    Y5_REQUIRE(c > 0 && c % 8 == 0 && x_ld % 8 == 0 && y_ld % 8 == 0 && x_ld >= c && y_ld >= c, "copy_channels: channels/pitches must be multiples of 8");
+    Y5_REQUIRE(pixels > 0, "copy_channels: empty tensor");
+    Y5_REQUIRE(y5_aligned16(x) && y5_aligned16(y), "copy_channels: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(copy_channels_kernel, dim3(grid_for(pixels * (c / 8))), dim3(kThreads), 0, s,
+                       static_cast<const f16*>(x), x_ld, static_cast<f16*>(y), y_ld, (long long)pixels, c / 8);
+    Y5_LAUNCH_CHECK("copy_channels_kernel");
+    return Y5_OK;
+}

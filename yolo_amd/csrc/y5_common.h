@@ -1,0 +1,46 @@
+// Shared declarations of the liby5hip.so translation units (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/y5hip.h"
+
+typedef _Float16 f16;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Records a failure for y5_last_error() and returns `code`.
+int y5_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define Y5_HIP(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return y5_fail(Y5_EHIP, "%s -> %s", #expr, hipGetErrorString(e_));  \
+    } while (0)
+
+#define Y5_REQUIRE(cond, ...)                              \
+    do {                                                   \
+        if (!(cond)) return y5_fail(Y5_EINVAL, __VA_ARGS__); \
+    } while (0)
+
+// Checks the launch that was just issued.
+#define Y5_LAUNCH_CHECK(name)                                                                      \
+    do {                                                                                           \
+        hipError_t e_ = hipGetLastError();                                                         \
+        if (e_ != hipSuccess) return y5_fail(Y5_EHIP, "launch %s -> %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+static inline bool y5_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Internal launchers (one per kernel family); the extern "C" entry points and the plan replay call these.
+int y5_launch_conv(const y5_conv_desc& d, hipStream_t s);
+int y5_launch_pack_image(const void* x, void* y, int batch, int c, int h, int w, int focus, int y_ld, hipStream_t s);
+int y5_launch_maxpool(const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c, int k, hipStream_t s);
+int y5_launch_upsample2x(const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c, int mode,
+                         hipStream_t s);
+int y5_launch_copy_channels(const void* x, int x_ld, void* y, int y_ld, int64_t pixels, int c, hipStream_t s);
+int y5_launch_decode(const y5_decode_desc& d, hipStream_t s);

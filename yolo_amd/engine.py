@@ -1,0 +1,615 @@
+"""Lowers a live models.yolo.Model into a launch plan of HIP kernels and runs it.
+
+What replaces what (reference call sites):
+  * Model.forward_once's module walk (models/yolo.py:107-130)      -> one y5_plan_run call
+  * Conv / fused Conv, Bottleneck add, BottleneckCSP incl. its concat BatchNorm,
+    SPP, Focus, nn.Upsample + Concat (models/common.py)            -> conv / pack / maxpool / upsample ops
+  * Detect head conv + decode (models/yolo.py:24-46)                -> conv + decode ops
+
+Data layout: every activation is NHWC fp16 in a private buffer; channel counts are padded to
+multiples of 8 with zero channels, so filter-pruned models with odd widths keep 16-byte vectors.
+A concatenation is a wider buffer whose producers write their channel slice directly; a tensor's
+`segs` list records (logical, padded) channel runs so that consumer weights can be packed to match.
+Shapes and parameters are read from the live modules (weight.shape, not the yaml), which is what
+makes pruned models work, and the plan is rebuilt whenever parameters change identity or version.
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.nn as nn
+
+from yolo_amd import _lib
+from yolo_amd.utils.torch_utils import bn_affine
+
+_DISABLED = [0]
+
+
+class disabled:
+    """Context manager that forces Model.forward onto the plain torch module walk (used by parity tests)."""
+
+    def __enter__(self):
+        _DISABLED[0] += 1
+
+    def __exit__(self, *exc):
+        _DISABLED[0] -= 1
+
+
+def pad8(c):
+    return (c + 7) // 8 * 8
+
+
+def _supported_types():
+    from yolo_amd.models import common, yolo
+    return (common.Conv, common.Bottleneck, common.BottleneckCSP, common.SPP, common.Focus, common.Concat,
+            yolo.Detect, nn.Upsample, nn.Sequential)
+
+
+def _has_hooks(model):
+    import torch.nn.modules.module as tm
+    if tm._global_forward_hooks or tm._global_forward_pre_hooks:
+        return True
+    for m in model.modules():
+        if m._forward_hooks or m._forward_pre_hooks:
+            return True
+    return False
+
+
+def eligible(model, x):
+    """True when this forward may run on the HIP engine: inference mode on a GPU in fp16, no autograd,
+    no module hooks (the pruning / FLOP-counting tools attach hooks and need the torch modules to run),
+    Detect.export off, 4-d input whose height and width are multiples of the largest stride."""
+    if _DISABLED[0] or model.training or torch.is_grad_enabled():
+        return False
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype is torch.float16 and x.dim() == 4):
+        return False
+    from yolo_amd.models.yolo import Detect
+    head = model.model[-1]
+    if not isinstance(head, Detect) or head.export or head.training:
+        return False
+    smax = int(max(head.stride)) if head.stride is not None else 32
+    if x.shape[2] % smax or x.shape[3] % smax:
+        return False
+    if _has_hooks(model):
+        return False
+    eng = _engine_of(model)
+    return eng.supported(x)
+
+
+def run(model, x):
+    return _engine_of(model).forward(x)
+
+
+def _engine_of(model):
+    eng = model.__dict__.get('_y5_engine')
+    if eng is None:
+        eng = Engine(model)
+        model.__dict__['_y5_engine'] = eng  # plain attribute: not a sub-module, not pickled state we rely on
+    return eng
+
+
+# --------------------------------------------------------------------------------------------
+class Act:
+    """An NHWC fp16 activation: channel slice [off, off + c_pad) of `buf` (pixel pitch ld)."""
+
+    def __init__(self, buf, off, ld, batch, h, w, segs):
+        self.buf, self.off, self.ld, self.batch, self.h, self.w = buf, off, ld, batch, h, w
+        self.segs = list(segs)  # [(logical channels, padded channels)]
+
+    @property
+    def c_pad(self):
+        return sum(p for _, p in self.segs)
+
+    @property
+    def c_log(self):
+        return sum(c for c, _ in self.segs)
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr() + 2 * self.off
+
+    def slice(self, off, segs):
+        return Act(self.buf, self.off + off, self.ld, self.batch, self.h, self.w, segs)
+
+
+class Unsupported(Exception):
+    pass
+
+
+def _conv_geometry(conv):
+    """(k, s) of an nn.Conv2d the conv kernel can run, else raises Unsupported."""
+    k, s, p = conv.kernel_size, conv.stride, conv.padding
+    if conv.groups != 1 or tuple(conv.dilation) != (1, 1) or conv.padding_mode != 'zeros':
+        raise Unsupported('grouped/dilated conv')
+    if k[0] != k[1] or s[0] != s[1] or k[0] not in (1, 3) or s[0] not in (1, 2):
+        raise Unsupported('conv kernel %s stride %s' % (k, s))
+    if isinstance(p, str) or tuple(p) != (k[0] // 2, k[0] // 2):
+        raise Unsupported('conv padding %s' % (p,))
+    return k[0], s[0]
+
+
+class Plan:
+    """A recorded launch plan for one (batch, height, width) plus the buffers it owns."""
+
+    def __init__(self, module, x, block=False):
+        """module: a models.yolo.Model, or with block=True a single Conv / Bottleneck / BottleneckCSP / SPP / Focus."""
+        self.lib = _lib.lib()
+        self.device = x.device
+        self.batch, self.cin, self.h, self.w = x.shape
+        self.keep = []          # tensors the plan's device pointers refer to
+        self.labels = []        # one human-readable label per op
+        self.homes = {}
+        handle = C.c_void_p()
+        _lib.check(self.lib.y5_plan_create(C.byref(handle)))
+        self.handle = handle
+        try:
+            if block:
+                self._build_block(module, x)
+            else:
+                self._build(module, x)
+        except Exception:
+            self.close()
+            raise
+
+    def close(self):
+        if self.handle:
+            self.lib.y5_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ allocation helpers
+    def _new_act(self, batch, h, w, segs):
+        c = sum(p for _, p in segs)
+        buf = torch.zeros(batch * h * w * c, dtype=torch.float16, device=self.device)
+        self.keep.append(buf)
+        return Act(buf, 0, c, batch, h, w, segs)
+
+    def _f32(self, t, n):
+        out = torch.zeros(n, dtype=torch.float32, device=self.device)
+        out[:t.numel()] = t.detach().float().reshape(-1)
+        self.keep.append(out)
+        return out
+
+    def _pack_weight(self, weight, segs):
+        """(Cout, Cin_logical, k, k) -> fp16 [rows128][kpad32], K index (r*k + q)*cin_pad + c following `segs`."""
+        cout, cin, k, _ = weight.shape
+        if cin != sum(c for c, _ in segs):
+            raise Unsupported('conv expects %d input channels, tensor has %d' % (cin, sum(c for c, _ in segs)))
+        cin_pad = sum(p for _, p in segs)
+        w = weight.detach().to(torch.float16).permute(0, 2, 3, 1)  # (Cout, k, k, Cin)
+        rows = (cout + 127) // 128 * 128
+        kk = k * k * cin_pad
+        kpad = (kk + 31) // 32 * 32
+        packed = torch.zeros(rows, kpad, dtype=torch.float16, device=self.device)
+        view = packed[:cout, :kk].view(cout, k, k, cin_pad)
+        src = dst = 0
+        for c, p in segs:
+            view[..., dst:dst + c] = w[..., src:src + c]
+            src += c
+            dst += p
+        self.keep.append(packed)
+        return packed, kpad, rows
+
+    # ------------------------------------------------------------------ op emitters
+    def _conv(self, label, x, conv, out, bias=None, affine=None, act=None, res=None):
+        """Record one convolution. conv: nn.Conv2d; out: Act slice to write; affine: (scale, shift) tensors."""
+        k, s = _conv_geometry(conv)
+        if conv.weight.dtype is not torch.float16 or conv.weight.device != self.device:
+            raise Unsupported('conv weights must be fp16 on the input device')
+        cout = conv.out_channels
+        if out.c_log != cout or len(out.segs) != 1:
+            raise Unsupported('conv output slice mismatch')
+        ho = (x.h + 2 * (k // 2) - k) // s + 1
+        wo = (x.w + 2 * (k // 2) - k) // s + 1
+        if (ho, wo) != (out.h, out.w):
+            raise Unsupported('conv output size mismatch')
+        packed, kpad, rows = self._pack_weight(conv.weight, x.segs)
+        d = _lib.ConvDesc()
+        d.x, d.w, d.y = x.ptr, packed.data_ptr(), out.ptr
+        cpad = out.c_pad
+        if bias is not None:
+            d.bias = self._f32(bias, cpad).data_ptr()
+        if affine is not None:
+            d.scale = self._f32(affine[0], cpad).data_ptr()
+            d.shift = self._f32(affine[1], cpad).data_ptr()
+        if res is not None:
+            if (res.c_pad, res.h, res.w) != (cpad, ho, wo):
+                raise Unsupported('residual shape mismatch')
+            d.res, d.res_ld = res.ptr, res.ld
+        d.batch, d.h, d.w_in, d.cin, d.x_ld = x.batch, x.h, x.w, x.c_pad, x.ld
+        d.ho, d.wo, d.cout, d.y_ld = ho, wo, cpad, out.ld
+        d.ksize, d.stride, d.pad = k, s, k // 2
+        d.kpad, d.w_rows = kpad, rows
+        if act is None or isinstance(act, nn.Identity):
+            d.act, d.slope = _lib.ACT_NONE, 0.0
+        elif isinstance(act, nn.LeakyReLU):
+            d.act, d.slope = _lib.ACT_LEAKY, float(act.negative_slope)
+        else:
+            raise Unsupported('activation %s' % type(act).__name__)
+        _lib.check(self.lib.y5_plan_add_conv(self.handle, C.byref(d)))
+        self.labels.append('%s conv%dx%d s%d %d->%d @%dx%d' % (label, k, k, s, x.c_log, cout, ho, wo))
+
+    def _conv_block(self, label, m, x, out, res=None):
+        """A models.common.Conv (conv + BatchNorm + activation, or its fused form)."""
+        if m.bn is None:
+            self._conv(label, x, m.conv, out, bias=m.conv.bias, act=m.act, res=res)
+        else:
+            if m.conv.bias is not None:
+                raise Unsupported('unfused Conv with conv bias')
+            self._conv(label, x, m.conv, out, affine=bn_affine(m.bn), act=m.act, res=res)
+
+    def _out_for(self, idx, batch, h, w, c_log):
+        """Destination of top-level layer idx: its slice of a later concat buffer, or a fresh buffer."""
+        home = self.homes.get(idx)
+        segs = [(c_log, pad8(c_log))]
+        if home is not None:
+            buf_act, off = home
+            if (buf_act.h, buf_act.w) == (h, w):
+                return buf_act.slice(off, segs)
+        return self._new_act(batch, h, w, segs)
+
+    # ------------------------------------------------------------------ graph lowering
+    def _build(self, model, x):
+        from yolo_amd.models import common, yolo
+        layers = list(model.model)
+        head = layers[-1]
+        B, H, W = self.batch, self.h, self.w
+
+        # ---- pass 1: logical channels / spatial size of every top-level output
+        shapes = []  # (c_log, h, w) or None for Detect
+        for i, m in enumerate(layers):
+            def src(j):
+                return (self.cin, H, W) if (i == 0 and j == -1) else shapes[i + j if j < 0 else j]
+            f = m.f
+            if isinstance(m, common.Focus):
+                c, h, w = src(f)
+                k, s = _conv_geometry(m.conv.conv)
+                shapes.append((m.conv.conv.out_channels, (h // 2 - 1) // s + 1, (w // 2 - 1) // s + 1))
+            elif isinstance(m, common.Conv):
+                c, h, w = src(f)
+                k, s = _conv_geometry(m.conv)
+                shapes.append((m.conv.out_channels, (h - 1) // s + 1, (w - 1) // s + 1))
+            elif isinstance(m, common.BottleneckCSP):
+                c, h, w = src(f)
+                shapes.append((m.cv4.conv.out_channels, h, w))
+            elif isinstance(m, common.SPP):
+                c, h, w = src(f)
+                shapes.append((m.cv2.conv.out_channels, h, w))
+            elif isinstance(m, common.Bottleneck):
+                c, h, w = src(f)
+                shapes.append((m.cv2.conv.out_channels, h, w))
+            elif isinstance(m, nn.Upsample):
+                c, h, w = src(f)
+                sf = m.scale_factor
+                sf = sf if isinstance(sf, (tuple, list)) else (sf, sf)
+                if m.size is not None or tuple(float(v) for v in sf) != (2.0, 2.0) or m.mode not in ('nearest', 'bilinear'):
+                    raise Unsupported('upsample %s x%s' % (m.mode, m.scale_factor))
+                if m.mode == 'bilinear' and m.align_corners:
+                    raise Unsupported('bilinear align_corners=True')
+                shapes.append((c, 2 * h, 2 * w))
+            elif isinstance(m, common.Concat):
+                if m.d != 1:
+                    raise Unsupported('concat dim %d' % m.d)
+                parts = [src(j) for j in f]
+                if len({(p[1], p[2]) for p in parts}) != 1:
+                    raise Unsupported('concat of different spatial sizes')
+                shapes.append((sum(p[0] for p in parts), parts[0][1], parts[0][2]))
+            elif isinstance(m, yolo.Detect):
+                shapes.append(None)
+            else:
+                raise Unsupported('module %s' % type(m).__name__)
+
+        # ---- pass 2: concat buffers and the in-place homes of their operands
+        self.homes = {}          # producer layer index -> (concat Act, channel offset)
+        self.concat_acts = {}    # concat layer index -> Act
+        producer_types = (common.Conv, common.Focus, common.BottleneckCSP, common.SPP, common.Bottleneck, nn.Upsample)
+        for i, m in enumerate(layers):
+            if not isinstance(m, common.Concat):
+                continue
+            srcs = [i + j if j < 0 else j for j in m.f]
+            segs = []
+            for j in srcs:
+                segs.extend(self.concat_acts[j].segs if j in self.concat_acts else [(shapes[j][0], pad8(shapes[j][0]))])
+            _, h, w = shapes[i]
+            act = self._new_act(B, h, w, segs)
+            self.concat_acts[i] = act
+            off = 0
+            for j in srcs:
+                width = self.concat_acts[j].c_pad if j in self.concat_acts else pad8(shapes[j][0])
+                if j not in self.homes and j not in self.concat_acts and isinstance(layers[j], producer_types):
+                    self.homes[j] = (act, off)
+                off += width
+
+        # ---- pass 3: emit ops
+        image = torch.zeros_like(x)  # stands for external slot 0 while recording
+        self.keep.append(image)
+        _lib.check(self.lib.y5_plan_bind_slot(self.handle, 0, image.data_ptr(), image.numel() * 2))
+        outs = [None] * len(layers)
+        for i, m in enumerate(layers):
+            name = '%d.%s' % (i, type(m).__name__)
+            f = m.f
+
+            def get(j):
+                return outs[i + j if j < 0 else j]
+            if isinstance(m, yolo.Detect):
+                self._detect(m, [get(j) for j in f])
+                continue
+            c_log, h, w = shapes[i]
+            if isinstance(m, common.Focus):
+                if i != 0 or f != -1:
+                    raise Unsupported('Focus must be the first layer')
+                packed = self._new_act(B, H // 2, W // 2, [(4 * self.cin, pad8(4 * self.cin))])
+                _lib.check(self.lib.y5_plan_add_pack_image(self.handle, image.data_ptr(), packed.ptr, B, self.cin, H, W, 1, packed.ld))
+                self.labels.append('%s pack focus' % name)
+                out = self._out_for(i, B, h, w, c_log)
+                self._conv_block(name, m.conv, packed, out)
+            elif isinstance(m, common.Conv):
+                if i == 0:
+                    xin = self._new_act(B, H, W, [(self.cin, pad8(self.cin))])
+                    _lib.check(self.lib.y5_plan_add_pack_image(self.handle, image.data_ptr(), xin.ptr, B, self.cin, H, W, 0, xin.ld))
+                    self.labels.append('%s pack nchw' % name)
+                else:
+                    xin = get(f)
+                out = self._out_for(i, B, h, w, c_log)
+                self._conv_block(name, m, xin, out)
+            elif isinstance(m, common.BottleneckCSP):
+                out = self._out_for(i, B, h, w, c_log)
+                self._csp(name, m, get(f), out)
+            elif isinstance(m, common.Bottleneck):
+                out = self._out_for(i, B, h, w, c_log)
+                self._bottleneck(name, m, get(f), out)
+            elif isinstance(m, common.SPP):
+                out = self._out_for(i, B, h, w, c_log)
+                self._spp(name, m, get(f), out)
+            elif isinstance(m, nn.Upsample):
+                xin = get(f)
+                out = self._out_for(i, B, h, w, c_log)
+                if len(xin.segs) != 1:
+                    out = self._new_act(B, h, w, xin.segs)
+                _lib.check(self.lib.y5_plan_add_upsample2x(self.handle, xin.ptr, xin.ld, out.ptr, out.ld, B, xin.h, xin.w,
+                                                            xin.c_pad, 0 if m.mode == 'nearest' else 1))
+                self.labels.append('%s upsample2x %s' % (name, m.mode))
+            elif isinstance(m, common.Concat):
+                out = self.concat_acts[i]
+                off = 0
+                for j in [i + j if j < 0 else j for j in f]:
+                    part = outs[j]
+                    if not (part.buf is out.buf and part.off == out.off + off):
+                        _lib.check(self.lib.y5_plan_add_copy_channels(self.handle, part.ptr, part.ld, out.ptr + 2 * off, out.ld,
+                                                                       B * h * w, part.c_pad))
+                        self.labels.append('%s copy part %d' % (name, j))
+                    off += part.c_pad
+            outs[i] = out
+
+    def _build_block(self, m, x):
+        """Lower one building block on an NCHW fp16 input (unit tests and debugging)."""
+        from yolo_amd.models import common
+        B, H, W = self.batch, self.h, self.w
+        image = torch.zeros_like(x)
+        self.keep.append(image)
+        _lib.check(self.lib.y5_plan_bind_slot(self.handle, 0, image.data_ptr(), image.numel() * 2))
+        focus = isinstance(m, common.Focus)
+        xin = self._new_act(B, H // 2 if focus else H, W // 2 if focus else W,
+                            [(4 * self.cin, pad8(4 * self.cin))] if focus else [(self.cin, pad8(self.cin))])
+        _lib.check(self.lib.y5_plan_add_pack_image(self.handle, image.data_ptr(), xin.ptr, B, self.cin, H, W, int(focus), xin.ld))
+        self.labels.append('pack')
+        conv = m.conv.conv if focus else (m.conv if isinstance(m, common.Conv) else m.cv4.conv if isinstance(m, common.BottleneckCSP)
+                                          else m.cv2.conv)
+        s = 1
+        if focus or isinstance(m, common.Conv):
+            s = _conv_geometry(conv)[1]
+        out = self._new_act(B, (xin.h - 1) // s + 1, (xin.w - 1) // s + 1, [(conv.out_channels, pad8(conv.out_channels))])
+        if focus:
+            self._conv_block('focus', m.conv, xin, out)
+        elif isinstance(m, common.Conv):
+            self._conv_block('conv', m, xin, out)
+        elif isinstance(m, common.Bottleneck):
+            self._bottleneck('bottleneck', m, xin, out)
+        elif isinstance(m, common.BottleneckCSP):
+            self._csp('csp', m, xin, out)
+        elif isinstance(m, common.SPP):
+            self._spp('spp', m, xin, out)
+        else:
+            raise Unsupported('block %s' % type(m).__name__)
+        self.block_out = out
+
+    def run_block(self, x):
+        """Execute a block plan; returns the NCHW fp16 result."""
+        arr = (C.c_void_p * 1)(x.contiguous().data_ptr())
+        _lib.check(self.lib.y5_plan_run(self.handle, arr, 1, _lib.current_stream()))
+        o = self.block_out
+        t = o.buf.view(o.batch, o.h, o.w, o.ld)[..., o.off:o.off + o.c_log]
+        return t.permute(0, 3, 1, 2).contiguous()
+
+    def _bottleneck(self, name, m, x, out):
+        hidden = self._new_act(x.batch, x.h, x.w, [(m.cv1.conv.out_channels, pad8(m.cv1.conv.out_channels))])
+        self._conv_block(name + '.cv1', m.cv1, x, hidden)
+        self._conv_block(name + '.cv2', m.cv2, hidden, out, res=x if m.add else None)
+
+    def _csp(self, name, m, x, out):
+        """BottleneckCSP (models/common.py:59-62): the BatchNorm + LeakyReLU that act on cat(y1, y2) are split per
+        half and folded into the epilogues of cv3 and cv2, which write straight into the concat buffer."""
+        if m.cv2.bias is not None or m.cv3.bias is not None:
+            raise Unsupported('CSP plain convs with bias')
+        c1 = m.cv1.conv.out_channels
+        t = self._new_act(x.batch, x.h, x.w, [(c1, pad8(c1))])
+        self._conv_block(name + '.cv1', m.cv1, x, t)
+        for bi, b in enumerate(m.m):
+            nxt = self._new_act(x.batch, x.h, x.w, [(b.cv2.conv.out_channels, pad8(b.cv2.conv.out_channels))])
+            self._bottleneck('%s.m%d' % (name, bi), b, t, nxt)
+            t = nxt
+        c3, c2 = m.cv3.out_channels, m.cv2.out_channels
+        if m.bn.num_features != c3 + c2:
+            raise Unsupported('CSP BatchNorm width')
+        cat = self._new_act(x.batch, x.h, x.w, [(c3, pad8(c3)), (c2, pad8(c2))])
+        scale, shift = bn_affine(m.bn)
+        self._conv(name + '.cv3', t, m.cv3, cat.slice(0, [(c3, pad8(c3))]), affine=(scale[:c3], shift[:c3]), act=m.act)
+        self._conv(name + '.cv2', x, m.cv2, cat.slice(pad8(c3), [(c2, pad8(c2))]), affine=(scale[c3:], shift[c3:]), act=m.act)
+        self._conv_block(name + '.cv4', m.cv4, cat, out)
+
+    def _spp(self, name, m, x, out):
+        """SPP (models/common.py:74-76). Pool sizes (5, 9, 13) are evaluated as a cascade of 5x5 pools, which is
+        exact for max; other size lists run each pool directly."""
+        ks = [p.kernel_size if isinstance(p.kernel_size, int) else p.kernel_size[0] for p in m.m]
+        for p, k in zip(m.m, ks):
+            st = p.stride if isinstance(p.stride, int) else p.stride[0]
+            pd = p.padding if isinstance(p.padding, int) else p.padding[0]
+            if st != 1 or pd != k // 2 or k % 2 != 1 or k > 13 or p.dilation != 1 or p.ceil_mode:
+                raise Unsupported('SPP pool k%d s%d p%d' % (k, st, pd))
+        c = m.cv1.conv.out_channels
+        seg = [(c, pad8(c))]
+        cat = self._new_act(x.batch, x.h, x.w, seg * (len(ks) + 1))
+        first = cat.slice(0, seg)
+        self._conv_block(name + '.cv1', m.cv1, x, first)
+        cascade = ks == [5, 9, 13]
+        for n, k in enumerate(ks):
+            src = cat.slice(n * pad8(c), seg) if cascade else first
+            dst = cat.slice((n + 1) * pad8(c), seg)
+            _lib.check(self.lib.y5_plan_add_maxpool(self.handle, src.ptr, src.ld, dst.ptr, dst.ld, x.batch, x.h, x.w, pad8(c),
+                                                    5 if cascade else k))
+            self.labels.append('%s maxpool%d' % (name, k))
+        self._conv_block(name + '.cv2', m.cv2, cat, out)
+
+    def _detect(self, m, feats):
+        B = self.batch
+        na, no = m.na, m.no
+        if na > _lib.Y5_MAX_ANCHORS:
+            raise Unsupported('more than %d anchors' % _lib.Y5_MAX_ANCHORS)
+        rows = [na * f.h * f.w for f in feats]
+        self.z_shape = (B, sum(rows), no)
+        self.x_shapes = [(B, na, f.h, f.w, no) for f in feats]
+        z = torch.zeros(self.z_shape, dtype=torch.float16, device=self.device)
+        xs = [torch.zeros(s, dtype=torch.float16, device=self.device) for s in self.x_shapes]
+        self.keep += [z] + xs
+        _lib.check(self.lib.y5_plan_bind_slot(self.handle, 1, z.data_ptr(), z.numel() * 2))
+        for i, t in enumerate(xs):
+            _lib.check(self.lib.y5_plan_bind_slot(self.handle, 2 + i, t.data_ptr(), t.numel() * 2))
+        row0 = 0
+        anchor_grid = m.anchor_grid.detach().float().cpu().view(m.nl, na, 2)
+        for i, f in enumerate(feats):
+            conv = m.m[i]
+            if conv.out_channels != na * no:
+                raise Unsupported('Detect conv width')
+            headbuf = self._new_act(B, f.h, f.w, [(na * no, pad8(na * no))])
+            self._conv('detect.m%d' % i, f, conv, headbuf, bias=conv.bias)
+            d = _lib.DecodeDesc()
+            d.head, d.head_ld = headbuf.ptr, headbuf.ld
+            d.x_out, d.z_out = xs[i].data_ptr(), z.data_ptr()
+            d.batch, d.ny, d.nx, d.na, d.no = B, f.h, f.w, na, no
+            d.z_rows_total, d.z_row0 = self.z_shape[1], row0
+            d.stride = float(m.stride[i])
+            for a in range(na):
+                d.anchor_wh[2 * a] = float(anchor_grid[i, a, 0])
+                d.anchor_wh[2 * a + 1] = float(anchor_grid[i, a, 1])
+            _lib.check(self.lib.y5_plan_add_decode(self.handle, C.byref(d)))
+            self.labels.append('detect.decode%d @%dx%d' % (i, f.h, f.w))
+            row0 += rows[i]
+
+    # ------------------------------------------------------------------ execution
+    def _ext(self, x, z, xs):
+        arr = (C.c_void_p * (2 + len(xs)))()
+        arr[0], arr[1] = x.data_ptr(), z.data_ptr()
+        for i, t in enumerate(xs):
+            arr[2 + i] = t.data_ptr()
+        return arr
+
+    def run(self, x):
+        z = torch.empty(self.z_shape, dtype=torch.float16, device=self.device)
+        xs = [torch.empty(s, dtype=torch.float16, device=self.device) for s in self.x_shapes]
+        ext = self._ext(x, z, xs)
+        _lib.check(self.lib.y5_plan_run(self.handle, ext, len(ext), _lib.current_stream()))
+        return z, xs
+
+    def profile(self, x):
+        """Per-op device milliseconds (hipEvent pairs on the current stream) with kind/FLOPs/bytes/labels."""
+        z = torch.empty(self.z_shape, dtype=torch.float16, device=self.device)
+        xs = [torch.empty(s, dtype=torch.float16, device=self.device) for s in self.x_shapes]
+        ext = self._ext(x, z, xs)
+        n = self.lib.y5_plan_num_ops(self.handle)
+        ms = (C.c_float * n)()
+        _lib.check(self.lib.y5_plan_profile(self.handle, ext, len(ext), _lib.current_stream(), ms, n))
+        rows = []
+        for i in range(n):
+            kind, flops, nbytes = C.c_int(), C.c_double(), C.c_double()
+            _lib.check(self.lib.y5_plan_op_info(self.handle, i, C.byref(kind), C.byref(flops), C.byref(nbytes)))
+            rows.append({'op': i, 'kind': _lib.OP_NAMES.get(kind.value, '?'), 'label': self.labels[i], 'ms': float(ms[i]),
+                         'flops': flops.value, 'bytes': nbytes.value})
+        return rows
+
+
+def run_block(module, x):
+    """Run one building block (Conv, Focus, Bottleneck, BottleneckCSP, SPP) through the HIP kernels.
+    x: (B, C, H, W) fp16 GPU tensor; module: fp16, eval mode, on the same device."""
+    with torch.cuda.device(x.device):
+        plan = Plan(module, x, block=True)
+        try:
+            return plan.run_block(x)
+        finally:
+            torch.cuda.synchronize()
+            plan.close()
+
+
+class Engine:
+    """Per-model cache of launch plans keyed by input shape and by the identity/version of every parameter."""
+
+    def __init__(self, model):
+        self.model = model
+        self.plans = {}
+        self.signature = None
+        self.unsupported = None   # (signature, reason) of the last failed lowering
+        self.calls = 0            # forwards executed by HIP kernels (read by tests)
+
+    def _signature(self):
+        sig = []
+        for t in list(self.model.parameters()) + list(self.model.buffers()):
+            sig.append((id(t), t.data_ptr(), t._version, t.dtype))
+        head = self.model.model[-1]
+        sig.append(tuple(float(s) for s in head.stride) if head.stride is not None else None)
+        return hash(tuple(sig))
+
+    def _plan(self, x):
+        sig = self._signature()
+        if sig != self.signature:
+            for p in self.plans.values():
+                p.close()
+            self.plans.clear()
+            self.signature = sig
+        key = (tuple(x.shape), x.device.index)
+        plan = self.plans.get(key)
+        if plan is None:
+            if self.unsupported is not None and self.unsupported[0] == (sig, key):
+                return None
+            try:
+                with torch.cuda.device(x.device):
+                    plan = Plan(self.model, x)
+            except Unsupported as e:
+                self.unsupported = ((sig, key), str(e))
+                return None
+            self.plans[key] = plan
+        return plan
+
+    def supported(self, x):
+        for m in self.model.model:
+            if not isinstance(m, _supported_types()):
+                return False
+        return self._plan(x) is not None
+
+    def forward(self, x):
+        plan = self._plan(x)
+        if plan is None:
+            raise _lib.Y5Error('model not supported by the HIP engine: %s' % (self.unsupported or ('', ''))[1])
+        x = x.contiguous()
+        with torch.cuda.device(x.device):
+            z, xs = plan.run(x)
+        self.calls += 1
+        return z, xs
+
+    def profile(self, x):
+        plan = self._plan(x)
+        with torch.cuda.device(x.device):
+            return plan.profile(x.contiguous())

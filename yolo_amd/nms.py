@@ -1,0 +1,96 @@
+"""Host driver of the HIP NMS kernels (yolo_amd/csrc/nms.hip) behind utils.utils.non_max_suppression.
+
+nms_padded() is the allocation-light batched form: fixed-size (B, max_det, 6) detections plus counts,
+all on the device and without a host synchronisation; nms() is the drop-in for
+torchvision.ops.boxes.nms on one box set.
+"""
+import ctypes as C
+
+import torch
+
+from yolo_amd import _lib
+
+MAX_DET = 300               # reference: utils/utils.py:578
+DEFAULT_CANDIDATES = 65536  # first-try candidate capacity per image; grows on demand
+
+
+def _class_mask(classes, nc, device):
+    if not classes:
+        return None
+    mask = torch.zeros(nc, dtype=torch.uint8)
+    for c in classes:
+        if 0 <= int(c) < nc:
+            mask[int(c)] = 1
+    return mask.to(device)
+
+
+def nms_padded(prediction, conf_thres=0.1, iou_thres=0.6, classes=None, agnostic=False, max_det=MAX_DET,
+               max_candidates=None, return_index=False, check_overflow=True):
+    """Run the batched pipeline on a (B, N, 5+nc) fp16/fp32 GPU tensor.
+
+    Returns (det, count) or (det, count, kept_index, n_candidates): det (B, max_det, 6) fp32 rows
+    [x1, y1, x2, y2, conf, cls] in descending confidence order, count (B,) int32.  With check_overflow
+    the per-image candidate totals are read back once and the call is repeated with a larger capacity
+    when an image produced more candidates than max_candidates; pass check_overflow=False (and inspect
+    n_candidates yourself) to stay asynchronous.
+    """
+    if not prediction.is_cuda:
+        raise _lib.Y5Error('nms_padded needs a GPU tensor')
+    if prediction.dtype not in (torch.float16, torch.float32):
+        prediction = prediction.float()
+    prediction = prediction.contiguous()
+    B, N, no = prediction.shape
+    nc = no - 5
+    lib = _lib.lib()
+    dev = prediction.device
+    if B == 0:
+        empty = (torch.zeros(0, max_det, 6, device=dev), torch.zeros(0, dtype=torch.int32, device=dev))
+        return empty + ((torch.zeros(0, max_det, dtype=torch.int32, device=dev), torch.zeros(0, dtype=torch.int32, device=dev)) if return_index else ())
+    cap = int(max_candidates or min(N * nc, DEFAULT_CANDIDATES))
+    mask = _class_mask(classes, nc, dev)
+    while True:
+        with torch.cuda.device(dev):
+            ws_bytes = lib.y5_nms_workspace_bytes(B, cap)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            det = torch.empty(B, max_det, 6, dtype=torch.float32, device=dev)
+            count = torch.empty(B, dtype=torch.int32, device=dev)
+            kept = torch.empty(B, max_det, dtype=torch.int32, device=dev)
+            ncand = torch.empty(B, dtype=torch.int32, device=dev)
+            d = _lib.NmsDesc()
+            d.pred = prediction.data_ptr()
+            d.class_keep = mask.data_ptr() if mask is not None else None
+            d.workspace, d.workspace_bytes = ws.data_ptr(), ws_bytes
+            d.det, d.count, d.kept_index, d.n_candidates = det.data_ptr(), count.data_ptr(), kept.data_ptr(), ncand.data_ptr()
+            d.iou_thres, d.conf_thres = float(iou_thres), float(conf_thres)
+            d.pred_dtype = 0 if prediction.dtype is torch.float16 else 1
+            d.batch, d.n_rows, d.no = B, N, no
+            d.agnostic = 1 if agnostic else 0
+            d.max_candidates, d.max_det = cap, max_det
+            _lib.check(lib.y5_nms_batched(C.byref(d), _lib.current_stream()))
+        if check_overflow:
+            worst = int(ncand.max().item())
+            if worst > cap:
+                cap = worst
+                continue
+        break
+    return (det, count, kept, ncand) if return_index else (det, count)
+
+
+def nms(boxes, scores, iou_thres, max_keep=MAX_DET):
+    """Greedy NMS of one box set on the GPU; returns the kept indices (int64) in descending score order,
+    truncated to max_keep, which is all non_max_suppression uses (utils/utils.py:627-629)."""
+    if not boxes.is_cuda:
+        raise _lib.Y5Error('nms needs GPU tensors')
+    lib = _lib.lib()
+    n = boxes.shape[0]
+    boxes = boxes.float().contiguous()
+    scores = scores.float().contiguous()
+    dev = boxes.device
+    with torch.cuda.device(dev):
+        keep = torch.empty(max_keep, dtype=torch.int64, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        ws_bytes = max(lib.y5_nms_workspace_bytes(1, max(n, 1)), 512)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        _lib.check(lib.y5_nms_boxes_f32(boxes.data_ptr(), scores.data_ptr(), n, float(iou_thres), keep.data_ptr(),
+                                        cnt.data_ptr(), max_keep, ws.data_ptr(), ws_bytes, _lib.current_stream()))
+    return keep[:int(cnt.item())]
