@@ -1,0 +1,184 @@
+"""Benchmark of the hot path: yolov5s 640x640 fp16, conv forward + Detect decode + NMS, images/s.
+
+  python bench.py [--gpus N --steps K --warmup W]          (N=1: plain process)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N>1: one rank per GPU)
+
+One step = one batch of synthetic images (already resident in HBM as fp16 NCHW) through the HIP launch
+plan (all convs, SPP, upsample/concat, head convs, decode) and the batched NMS kernels, ending with padded
+detections + counts on the device; with N>1 each rank processes its own batch (weak scaling) and the step
+ends with the RCCL all_gather of the detection blocks.  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+PEAK_MFMA_TFLOPS = 2500.0   # dense fp16 MFMA peak of one MI355X
+PEAK_HBM_GBS = 8000.0       # HBM3E peak of one MI355X
+
+
+def build_model(name, device):
+    import util  # tests/util.py: seeded construction + BatchNorm calibration + head gain (synthetic weights)
+    model = util.build_model(name, seed=0)
+    util.calibrate(model, seed=1, size=640, head_gain=2.0)
+    fp32_fused = util.quiet(model.fuse).eval()
+    import copy
+    cpu_sd = {k: v.clone() for k, v in fp32_fused.state_dict().items()}
+    gpu_model = copy.deepcopy(fp32_fused).half().to(device).eval()
+    return gpu_model, cpu_sd, float(max(fp32_fused.stride))
+
+
+def cpu_baseline(name, cpu_sd, strides, conf, iou, budget_s=12.0, batch=8):
+    """The CPU oracle (torch-CPU fp32 restatement of the reference + C NMS) on a bounded sample of the same workload."""
+    import yaml
+    from oracle import y5ref, nms_c
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    cfg = yaml.safe_load(open(os.path.join(ROOT, 'yolo_amd', 'models', name + '.yaml')))
+    g = torch.Generator().manual_seed(1)
+    done, t_total = 0, 0.0
+    with torch.no_grad():
+        while t_total < budget_s and done < 16 * batch:
+            x = torch.rand(batch, 3, 640, 640, generator=g).half().float()
+            t0 = time.time()
+            z, _ = y5ref.forward(cfg, cpu_sd, x, precision='fp32', strides=strides)
+            nms_c.non_max_suppression(z.numpy(), conf, iou)
+            t_total += time.time() - t0
+            done += batch
+    return {'value': round(done / t_total, 2), 'unit': 'images/s', 'cores': threads, 'kind': 'port',
+            'sample': '%d images of the same synthetic 640x640 workload in batches of %d (fp32 torch-CPU forward+decode, C NMS)' % (done, batch)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--model', default='yolov5s')
+    ap.add_argument('--batch', type=int, default=32, help='images per GPU and step')
+    ap.add_argument('--conf', type=float, default=0.001)
+    ap.add_argument('--iou', type=float, default=0.65)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--profile-passes', type=int, default=5)
+    args = ap.parse_args()
+
+    from yolo_amd import dist as ydist
+    rank, world, local = ydist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit('bench: --gpus %d but WORLD_SIZE is %d (launch N>1 with torch.distributed.run)' % (args.gpus, world))
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+    torch.set_grad_enabled(False)
+
+    from yolo_amd import engine, nms as hip_nms
+    import torch.distributed as dist
+    model, cpu_sd, _ = build_model(args.model, device)
+    strides = model.stride
+    g = torch.Generator().manual_seed(1 + rank)
+    x = torch.rand(args.batch, 3, 640, 640, generator=g).half().to(device)
+
+    def step():
+        z, _ = model(x)
+        det, count, kept, ncand = hip_nms.nms_padded(z, args.conf, args.iou, return_index=True, check_overflow=False)
+        if world > 1:
+            det, count = ydist.gather_detections(det, count)
+        return det, count, ncand
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    eng = model.__dict__['_y5_engine']
+    if eng.calls < args.warmup:
+        raise SystemExit('bench: forward did not run on the HIP engine')
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    det, count, ncand = out
+    cand = ncand.float().mean().item()
+    kept = count.float().mean().item()
+    if int(ncand.max().item()) > hip_nms.DEFAULT_CANDIDATES:
+        raise SystemExit('bench: candidate capacity overflow, result invalid')
+
+    record = None
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        value = args.batch * world * args.steps / elapsed
+        # ---- per-kernel device time from hipEvent pairs around every launch of the plan (same stream)
+        acc = None
+        for _ in range(args.profile_passes):
+            rows = eng.profile(x)
+            if acc is None:
+                acc = rows
+            else:
+                for a, r in zip(acc, rows):
+                    a['ms'] += r['ms']
+        for a in acc:
+            a['ms'] /= args.profile_passes
+        conv = [a for a in acc if a['kind'] == 'conv']
+        conv_ms = sum(a['ms'] for a in conv)
+        conv_flops = sum(a['flops'] for a in conv)
+        dec = [a for a in acc if a['kind'] == 'decode']
+        dec_ms = sum(a['ms'] for a in dec)
+        dec_bytes = sum(a['bytes'] for a in dec)
+        plan_ms = sum(a['ms'] for a in acc)
+        # NMS stage timed as a whole with events on the same stream
+        z, _ = model(x)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.profile_passes):
+            hip_nms.nms_padded(z, args.conf, args.iou, check_overflow=False)
+        e1.record()
+        torch.cuda.synchronize()
+        nms_ms = e0.elapsed_time(e1) / args.profile_passes
+        achieved = conv_flops / (conv_ms * 1e-3) / 1e12
+        top = sorted(conv, key=lambda a: -a['ms'])[:6]
+        record = {
+            'metric': 'images/sec at 640x640 fp16 (conv fwd+decode+NMS)', 'value': round(value, 1), 'unit': 'images/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_step, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
+            'config': {'workload': '%s 640x640 fp16 batch %d per GPU, conf %g iou %g (test.py setting), random-init weights, '
+                                   'BatchNorm-calibrated, head gain 2.0' % (args.model, args.batch, args.conf, args.iou),
+                       'global_batch': args.batch * world, 'parallelism': 'batch shard x%d, detection all_gather' % world,
+                       'candidates_per_image': round(cand, 1), 'kept_per_image': round(kept, 1)},
+            'roofline': {'kernel': 'conv_igemm_kernel (all %d conv launches of one forward)' % len(conv), 'bound': 'mfma',
+                         'achieved': round(achieved, 2), 'peak': PEAK_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / PEAK_MFMA_TFLOPS, 4), 'traffic': None,
+                         'flops_per_forward': conv_flops, 'ms_per_forward': round(conv_ms, 4)},
+            'stages': {'plan_ms': round(plan_ms, 4), 'conv_ms': round(conv_ms, 4), 'decode_ms': round(dec_ms, 4),
+                       'nms_ms': round(nms_ms, 4),
+                       'decode_hbm': {'bound': 'hbm', 'achieved': round(dec_bytes / (dec_ms * 1e-3) / 1e9, 1), 'peak': PEAK_HBM_GBS,
+                                      'unit': 'GB/s', 'frac': round(dec_bytes / (dec_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},
+                       'top_convs': [{'label': a['label'], 'ms': round(a['ms'], 4),
+                                      'tflops': round(a['flops'] / (a['ms'] * 1e-3) / 1e12, 1)} for a in top]},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            record['cpu_baseline'] = cpu_baseline(args.model, cpu_sd, strides, args.conf, args.iou)
+        elif world == 1:
+            record['cpu_baseline'] = None
+        print(json.dumps(record))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

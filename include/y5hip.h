@@ -75,7 +75,7 @@ typedef struct y5_conv_desc {
     int32_t batch, h, w_in, cin, x_ld;
     int32_t ho, wo, cout, y_ld, res_ld;
     int32_t ksize, stride, pad; /* ksize in {1,3}; stride in {1,2}; pad = ksize/2                  */
-    int32_t kpad;               /* >= ksize*ksize*cin, multiple of 32                               */
+    int32_t kpad;               /* >= ksize*ksize*cin, multiple of 64                               */
     int32_t w_rows;             /* >= cout, multiple of 128                                         */
     int32_t act;                /* Y5_ACT_*                                                         */
     float slope;                /* LeakyReLU negative slope (0.1 in the reference)                  */

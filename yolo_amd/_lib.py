@@ -83,6 +83,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise Y5Error('liby5hip.so not found at %s - build it with `make -C yolo_amd/csrc` '
                           '(hipcc --offload-arch=gfx950); the GPU path has no fallback' % LIB_PATH)
+        # torch bundles its own HIP runtime (same soname as /opt/rocm's). Import torch first so that the dynamic
+        # linker binds this library to the runtime instance torch uses; two runtimes in one process do not see
+        # each other's devices, streams or allocations.
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError here means the .so is stale

@@ -3,16 +3,37 @@
 //
 // GEMM view:  D[n][m] = sum_k Wt[n][k] * X[m][k]
 //   m = (b, oy, ox) output pixel, n = output channel, k = (r*ks + q)*cin + c.
-// One 256-thread workgroup (4 waves) owns a BM-pixel x BN-channel tile and walks K in steps of 32:
-// the X tile is gathered (im2col on the fly, zero for padding) and the Wt tile copied with 16-byte
-// global loads into registers, written to a double-buffered LDS image with a 16-byte XOR swizzle,
-// and consumed by v_mfma_f32_32x32x16_f16 with the weights as the row operand, so that every lane
-// ends up holding 4 consecutive channels of one pixel per accumulator group.  The epilogue applies
-// the per-channel post-ops in fp32 with the reference's fp16 rounding points, stages the tile in
-// LDS and writes whole 16-byte channel vectors, adding the residual there.
+// One 256-thread workgroup (4 waves) owns a BM-pixel x BN-channel tile and walks K in steps of BK
+// (32 or 64): the X tile is gathered (im2col on the fly, a zero page for padding) and the Wt tile copied
+// by 16-byte global->LDS DMA into an S-deep ring of LDS stages, S-1 steps ahead of the MFMAs, with
+// hand-counted s_waitcnt vmcnt and one barrier per step.  The LDS image is lane-linear per DMA
+// instruction; a 16-byte XOR swizzle (applied to the source chunk and to the read address) keeps the
+// ds_read_b128 fragment reads bank-conflict free.  v_mfma_f32_32x32x16_f16 takes the weights as the
+// row operand, so every lane ends up holding 4 consecutive channels of one pixel per accumulator
+// group.  The epilogue applies the per-channel post-ops on those groups of four with the reference's
+// fp16 rounding points, stages the tile in LDS and writes whole 16-byte channel vectors, adding the
+// residual there.
 #include "y5_common.h"
 
 namespace {
+
+struct FastDiv {  // n / d for 0 <= n < 2^31 by multiply-high and shift
+    unsigned mul, shr, d;
+};
+
+FastDiv make_fastdiv(unsigned d) {
+    FastDiv f{0u, 0u, d};
+    if (d > 1) {
+        unsigned lg = 0;
+        while ((1ull << lg) < d) ++lg;
+        const unsigned p = 31 + lg;
+        f.mul = (unsigned)(((1ull << p) + d - 1) / d);
+        f.shr = p - 32;
+    }
+    return f;
+}
+
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) { return f.d == 1 ? n : (__umulhi(n, f.mul) >> f.shr); }
 
 struct ConvArgs {
     const f16* x;
@@ -25,14 +46,13 @@ struct ConvArgs {
     long long M;  // batch*ho*wo
     int H, W, Cin, x_ld;
     int Ho, Wo, Cout, y_ld, res_ld;
-    int stride, pad, K, kpad;
+    int stride, pad, K;
+    int w_ld;     // weight row pitch in elements
+    int nk;       // K-steps to walk
     int tiles_n, tiles_total;
-    int act;
-    float slope;
+    float slope;  // 1.0 = no activation: leaky(v) = max(v, slope*v) for 0 < slope <= 1
+    FastDiv div_hw, div_wo, div_cin;
 };
-
-constexpr int BK = 32;          // K elements per step (four 16-byte chunks per tile row)
-constexpr int ROW_BYTES = 64;   // LDS bytes per tile row and step
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     // Workgroups are dealt round-robin over the 8 XCDs; give each XCD one contiguous run of tiles
@@ -42,102 +62,156 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return start + (bid >> 3);
 }
 
-__device__ __forceinline__ f16 post_op(float v, int n, const ConvArgs& a) {
-    if (a.bias) v += a.bias[n];
-    f16 h = (f16)v;
-    if (a.scale) h = (f16)((float)h * a.scale[n] + a.shift[n]);
-    if (a.act == Y5_ACT_LEAKY) {
-        const float f = (float)h;
-        h = (f16)(f > 0.f ? f : f * a.slope);
-    }
-    return h;
+// 64 bytes of zeros: the source of every out-of-image / out-of-range 16-byte chunk, so that the
+// LDS-DMA below can always write a full tile without branching.
+__device__ __attribute__((aligned(64))) unsigned int y5_zero_page[16];
+
+// One 16-byte-per-lane global -> LDS DMA (global_load_lds_dwordx4): the wave writes 1 KiB starting at the
+// wave-uniform LDS byte address lds_base, lane i at lds_base + 16*i, from each lane's own source address.
+// Issued from inline asm so that the compiler neither counts it nor drains it before later LDS reads;
+// completion is tracked by hand with s_waitcnt vmcnt(N).
+__device__ __forceinline__ void dma16(const void* src, unsigned lds_base) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(lds_base)
+        : "memory");
 }
 
-template <int BM, int BN, int WM, int WN, int KS>
+// Wait until at most n of this wave's vector-memory operations are outstanding, then meet the workgroup.
+__device__ __forceinline__ void wait_vm_and_barrier(int n) {
+#define Y5_WAIT_CASE(N) \
+    case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    switch (n) {
+        Y5_WAIT_CASE(1) Y5_WAIT_CASE(2) Y5_WAIT_CASE(3) Y5_WAIT_CASE(4) Y5_WAIT_CASE(5) Y5_WAIT_CASE(6)
+        Y5_WAIT_CASE(8) Y5_WAIT_CASE(9) Y5_WAIT_CASE(10) Y5_WAIT_CASE(12) Y5_WAIT_CASE(16)
+        default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    }
+#undef Y5_WAIT_CASE
+}
+
+// Post-ops on four consecutive channels n..n+3 of one pixel (n % 4 == 0, n + 3 < Cout).
+__device__ __forceinline__ f16x4 post_op4(f32x4 v, int n, const ConvArgs& a) {
+    if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
+    f16x4 h = __builtin_convertvector(v, f16x4);
+    if (a.scale) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + n), sh = *reinterpret_cast<const f32x4*>(a.shift + n);
+        h = __builtin_convertvector(__builtin_convertvector(h, f32x4) * sc + sh, f16x4);
+    }
+    const f16x4 t = __builtin_convertvector(__builtin_convertvector(h, f32x4) * a.slope, f16x4);
+    return __builtin_elementwise_max(h, t);
+}
+
+// BM x BN output tile, WM x WN waves, KS in {1,3}, S-deep LDS ring of BK-wide K-steps filled by DMA S-1 steps
+// ahead.  DIRECT: 1x1 stride-1 convolution, where output pixel m reads input pixel m (no coordinate decode).
+template <int BM, int BN, int WM, int WN, int KS, int S, int BK, bool DIRECT>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     static_assert(WM * WN == 4, "four waves per workgroup");
+    static_assert(BK == 32 || BK == 64, "K-step is 32 or 64");
+    static_assert(!DIRECT || KS == 1, "direct addressing is for 1x1 convolutions");
     constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile: pixels x channels
     constexpr int RM = WTM / 32, RN = WTN / 32;  // 32x32 MFMA tiles per wave
     static_assert(RM >= 1 && RN >= 1, "wave tile must hold at least one MFMA tile");
-    constexpr int A_CH = BM * 4 / 256;               // 16-byte activation chunks per thread and step
-    constexpr int B_CH = (BN * 4 + 255) / 256;       // 16-byte weight chunks per thread and step
+    constexpr int ROW_BYTES = BK * 2;            // LDS bytes per tile row and step
+    constexpr int CPRW = BK / 8;                 // 16-byte chunks per tile row (4 or 8)
+    constexpr int RPI = 256 / CPRW;              // tile rows one DMA instruction of the workgroup covers (64 or 32)
+    constexpr bool B_HALF = BN * CPRW < 256;     // weight tile smaller than one workgroup-wide DMA: waves 0,1 only
+    static_assert(BM % RPI == 0 && (BN % RPI == 0 || BN * CPRW == 128), "tile rows are staged RPI at a time");
+    constexpr int A_CH = BM / RPI;               // DMA instructions per wave and K-step for activations
+    constexpr int B_CH = (BN + RPI - 1) / RPI;   // ... for weights
     constexpr int STAGE_BYTES = (BM + BN) * ROW_BYTES;
-    constexpr int EP = BN * 2 + 16;                  // epilogue row pitch in bytes
-    constexpr int SMEM = (2 * STAGE_BYTES > BM * EP) ? 2 * STAGE_BYTES : BM * EP;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+    constexpr int EP = BN * 2 + 16;              // epilogue row pitch in bytes
+    constexpr int SMEM = (S * STAGE_BYTES > BM * EP) ? S * STAGE_BYTES : BM * EP;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
 
     const int t = threadIdx.x;
     const int lane = t & 63;
-    const int wave = t >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave % WM, wn = wave / WM;
 
     const int tile = xcd_remap(blockIdx.x, a.tiles_total);
     const int mt = tile / a.tiles_n, nt = tile - mt * a.tiles_n;
-    const long long m0 = (long long)mt * BM;
+    const int m0 = mt * BM;  // M < 2^31 is checked by the launcher
     const int n0 = nt * BN;
 
-    // ---- per-thread gather state: each thread owns chunk column kc of A_CH activation rows ----
-    const int kc = t & 3;
-    const int row0 = t >> 2;  // 0..63
+    // ---- per-thread gather state.  Thread t fills LDS slot (row = t/CPRW [+RPI*i], 16-byte slot t%CPRW) of
+    // every stage; with the XOR swizzle that slot holds K-chunk kc of the row.
+    const int row0 = t / CPRW;
+    const int kc = (BK == 64) ? ((t & 7) ^ ((row0 >> 1) & 7)) : ((t & 3) ^ ((row0 >> 2) & 3));
     int hi0[A_CH], wi0[A_CH];
-    long long pix0[A_CH];  // pixel index of (b, 0, 0)
+    const f16* xrow[A_CH];  // DIRECT: pointer to the pixel; otherwise to pixel (b, 0, 0)
     bool mvalid[A_CH];
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
-        const long long m = m0 + row0 + 64 * i;
+        const int m = m0 + row0 + RPI * i;
         mvalid[i] = m < a.M;
-        const long long mm = mvalid[i] ? m : 0;
-        const int hw = a.Ho * a.Wo;
-        const long long b = mm / hw;
-        const int rem = (int)(mm - b * hw);
-        const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-        hi0[i] = oy * a.stride - a.pad;
-        wi0[i] = ox * a.stride - a.pad;
-        pix0[i] = b * (long long)a.H * a.W;
+        const unsigned mm = mvalid[i] ? (unsigned)m : 0u;
+        if (DIRECT) {
+            hi0[i] = wi0[i] = 0;
+            xrow[i] = a.x + (size_t)mm * a.x_ld;
+        } else {
+            const unsigned b = fdiv(mm, a.div_hw);
+            const unsigned rem = mm - b * (unsigned)(a.Ho * a.Wo);
+            const unsigned oy = fdiv(rem, a.div_wo), ox = rem - oy * (unsigned)a.Wo;
+            hi0[i] = (int)oy * a.stride - a.pad;
+            wi0[i] = (int)ox * a.stride - a.pad;
+            xrow[i] = a.x + (size_t)b * a.H * a.W * a.x_ld;
+        }
     }
-    const f16* wrow[B_CH];
+    const bool bload = !B_HALF || (wave < 2);  // wave-uniform
+    const f16* wptr[B_CH];
 #pragma unroll
-    for (int i = 0; i < B_CH; ++i) wrow[i] = a.w + (size_t)(n0 + row0 + 64 * i) * a.kpad + kc * 8;
-    const bool bload = (BN * 4 >= 256) || (t < BN * 4);
+    for (int i = 0; i < B_CH; ++i) wptr[i] = a.w + (size_t)(n0 + (bload ? row0 : 0) + RPI * i) * a.w_ld + kc * 8;
+    const int lps = A_CH + (bload ? B_CH : 0);  // DMA instructions this wave issues per K-step
 
-    uint4 areg[A_CH], breg[B_CH];
-    auto load_tiles = [&](int k0) {
-        const int k = k0 + kc * 8;
-        int r = 0, q = 0, c = k;
+    // running K position of this thread's chunk
+    int kpos = kc * 8, tap = 0, cch = kpos;
+    if (KS > 1) {
+        tap = (int)fdiv((unsigned)kpos, a.div_cin);
+        cch = kpos - tap * a.Cin;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+    auto issue = [&](int stage) {
+        int r = 0, q = 0;
         if (KS > 1) {
-            const int tap = k / a.Cin;
-            c = k - tap * a.Cin;
-            r = tap / KS;
-            q = tap - r * KS;
+            r = (tap * 11) >> 5;  // tap / 3 for tap < 32
+            q = tap - 3 * r;
         }
-        const bool kvalid = k < a.K;
+        const bool kvalid = kpos < a.K;
+        const unsigned abase = lds0 + stage * STAGE_BYTES + wave * 1024;
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) {
-            const int hi = hi0[i] + r, wi = wi0[i] + q;
-            const bool ok = kvalid && mvalid[i] && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ok) v = *reinterpret_cast<const uint4*>(a.x + (size_t)(pix0[i] + (long long)hi * a.W + wi) * a.x_ld + c);
-            areg[i] = v;
+            const void* src;
+            if (DIRECT) {
+                src = (kvalid && mvalid[i]) ? (const void*)(xrow[i] + kpos) : (const void*)y5_zero_page;
+            } else {
+                const int hi = hi0[i] + r, wi = wi0[i] + q;
+                const bool ok = kvalid && mvalid[i] && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+                src = ok ? (const void*)(xrow[i] + (size_t)(hi * a.W + wi) * a.x_ld + cch) : (const void*)y5_zero_page;
+            }
+            dma16(src, abase + i * 4096);
         }
+        if (bload) {
+            const unsigned bbase = lds0 + stage * STAGE_BYTES + BM * ROW_BYTES + wave * 1024;
 #pragma unroll
-        for (int i = 0; i < B_CH; ++i) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (bload) v = *reinterpret_cast<const uint4*>(wrow[i] + k0);
-            breg[i] = v;
+            for (int i = 0; i < B_CH; ++i) {
+                dma16(wptr[i], bbase + i * 4096);
+                wptr[i] += BK;
+            }
         }
-    };
-    auto store_tiles = [&](int stage) {
-        unsigned char* A = smem + stage * STAGE_BYTES;
-        unsigned char* B = A + BM * ROW_BYTES;
-#pragma unroll
-        for (int i = 0; i < A_CH; ++i) {
-            const int row = row0 + 64 * i;
-            *reinterpret_cast<uint4*>(A + row * ROW_BYTES + ((kc ^ ((row >> 2) & 3)) << 4)) = areg[i];
-        }
-#pragma unroll
-        for (int i = 0; i < B_CH; ++i) {
-            const int row = row0 + 64 * i;
-            if (bload) *reinterpret_cast<uint4*>(B + row * ROW_BYTES + ((kc ^ ((row >> 2) & 3)) << 4)) = breg[i];
+        kpos += BK;
+        if (KS > 1) {
+            cch += BK;
+            while (cch >= a.Cin) {
+                cch -= a.Cin;
+                ++tap;
+            }
         }
     };
 
@@ -150,19 +224,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
             for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
 
     const int lr = lane & 31, lh = lane >> 5;
-    const int sw = (lr >> 2) & 3;  // tile rows handled by a wave start at multiples of 32
-    const int nk = a.kpad / BK;
+    const int sw = (BK == 64) ? ((lr >> 1) & 7) : ((lr >> 2) & 3);  // wave tile rows start at multiples of 32
+    const int nk = a.nk;
 
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < S - 1; ++s)
+        if (s < nk) issue(s);
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load_tiles((kt + 1) * BK);
-        const unsigned char* A = smem + cur * STAGE_BYTES;
+        // K-steps kt+1 .. min(kt+S-2, nk-1) may stay in flight; step kt must have landed for every wave
+        int ahead = nk - 1 - kt;
+        if (ahead > S - 2) ahead = S - 2;
+        wait_vm_and_barrier(ahead * lps);
+        if (kt + S - 1 < nk) issue((kt + S - 1) % S);
+        const unsigned char* A = smem + (kt % S) * STAGE_BYTES;
         const unsigned char* B = A + BM * ROW_BYTES;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < BK / 16; ++ks) {
             const int coff = ((2 * ks + lh) ^ sw) << 4;
             f16x8 xf[RM], wf[RN];
 #pragma unroll
@@ -177,13 +254,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
                 for (int i = 0; i < RM; ++i)
                     acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], xf[i], acc[j][i], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tiles(cur ^ 1);
-        __syncthreads();
     }
+    wait_vm_and_barrier(0);  // every wave is done reading the ring before the epilogue reuses it
 
     // ---- epilogue: post-ops in registers -> fp16 tile in LDS -> 16-byte stores (+ residual) ----
-    // accumulator element e of tile (j,i): channel = 8*(e>>2) + 4*lh + (e&3) within the 32-channel
-    // MFMA tile, pixel = lr.
+    // accumulator element e of MFMA tile (j,i): channel = 8*(e>>2) + 4*lh + (e&3) within the 32-channel
+    // tile, pixel = lr; elements 4g..4g+3 are four consecutive channels.
 #pragma unroll
     for (int j = 0; j < RN; ++j) {
 #pragma unroll
@@ -193,11 +269,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
             if (n < a.Cout) {
 #pragma unroll
                 for (int i = 0; i < RM; ++i) {
-                    f16x4 h;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) h[e] = post_op(acc[j][i][4 * g + e], n + e, a);
+                    const f32x4 v = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
                     const int ml = wm * WTM + i * 32 + lr;
-                    *reinterpret_cast<f16x4*>(smem + ml * EP + nl * 2) = h;
+                    *reinterpret_cast<f16x4*>(smem + ml * EP + nl * 2) = post_op4(v, n, a);
                 }
             }
         }
@@ -211,7 +285,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int p = 0; p < BM / RPP; ++p) {
             const int row = rr + p * RPP;
-            const long long m = m0 + row;
+            const int m = m0 + row;
             if (m < a.M) {
                 f16x8 v = *reinterpret_cast<const f16x8*>(smem + row * EP + cc * 16);
                 if (a.res) v += *reinterpret_cast<const f16x8*>(a.res + (size_t)m * a.res_ld + n);
@@ -221,18 +295,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     }
 }
 
-template <int BM, int BN, int WM, int WN>
-int launch_tile(const ConvArgs& a0, int ksize, hipStream_t s) {
+template <int BM, int BN, int WM, int WN, int S, int BK>
+int launch_tile(const ConvArgs& a0, int ksize, bool direct, hipStream_t s) {
     ConvArgs a = a0;
     const long long tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.Cout + BN - 1) / BN;
+    a.nk = (a.K + BK - 1) / BK;  // the weight rows are zero-padded to a multiple of 64 >= K
     const long long total = tiles_m * a.tiles_n;
     if (total <= 0 || total > 0x7fffffffLL) return y5_fail(Y5_EINVAL, "conv: tile count %lld out of range", total);
     a.tiles_total = (int)total;
-    if (ksize == 1)
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1>), dim3((unsigned)total), dim3(256), 0, s, a);
+    const dim3 grid((unsigned)total), block(256);
+    if (ksize == 3)
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 3, S, BK, false>), grid, block, 0, s, a);
+    else if (direct)
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1, S, BK, true>), grid, block, 0, s, a);
     else
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 3>), dim3((unsigned)total), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1, S, BK, false>), grid, block, 0, s, a);
     Y5_LAUNCH_CHECK("conv_igemm_kernel");
     return Y5_OK;
 }
@@ -245,16 +323,19 @@ int y5_launch_conv(const y5_conv_desc& d, hipStream_t s) {
     Y5_REQUIRE(d.stride == 1 || d.stride == 2, "conv: stride %d not in {1,2}", d.stride);
     Y5_REQUIRE(d.pad == d.ksize / 2, "conv: pad %d != ksize/2", d.pad);
     Y5_REQUIRE(d.batch > 0 && d.h > 0 && d.w_in > 0 && d.ho > 0 && d.wo > 0, "conv: empty tensor");
+    Y5_REQUIRE((long long)d.batch * d.ho * d.wo < 0x7fffffffLL && (long long)d.h * d.w_in < 0x7fffffffLL, "conv: more than 2^31 pixels");
     Y5_REQUIRE(d.ho == (d.h + 2 * d.pad - d.ksize) / d.stride + 1 && d.wo == (d.w_in + 2 * d.pad - d.ksize) / d.stride + 1,
                "conv: output %dx%d inconsistent with input %dx%d k%d s%d", d.ho, d.wo, d.h, d.w_in, d.ksize, d.stride);
     Y5_REQUIRE(d.cin > 0 && d.cin % 8 == 0 && d.x_ld % 8 == 0 && d.x_ld >= d.cin, "conv: cin %d / x_ld %d must be multiples of 8", d.cin, d.x_ld);
     Y5_REQUIRE(d.cout > 0 && d.cout % 8 == 0 && d.y_ld % 8 == 0 && d.y_ld >= d.cout, "conv: cout %d / y_ld %d must be multiples of 8", d.cout, d.y_ld);
-    Y5_REQUIRE(d.kpad % 32 == 0 && d.kpad >= d.ksize * d.ksize * d.cin, "conv: kpad %d too small or not a multiple of 32", d.kpad);
+    Y5_REQUIRE(d.kpad % 64 == 0 && d.kpad >= d.ksize * d.ksize * d.cin, "conv: kpad %d too small or not a multiple of 64", d.kpad);
     Y5_REQUIRE(d.w_rows % 128 == 0 && d.w_rows >= d.cout, "conv: w_rows %d must be a multiple of 128 >= cout", d.w_rows);
     Y5_REQUIRE(!d.scale || d.shift, "conv: scale without shift");
     Y5_REQUIRE(!d.res || (d.res_ld % 8 == 0 && d.res_ld >= d.cout), "conv: bad residual pitch %d", d.res_ld);
     Y5_REQUIRE(y5_aligned16(d.x) && y5_aligned16(d.w) && y5_aligned16(d.y) && y5_aligned16(d.res), "conv: pointers must be 16-byte aligned");
+    Y5_REQUIRE(y5_aligned16(d.bias) && y5_aligned16(d.scale) && y5_aligned16(d.shift), "conv: per-channel vectors must be 16-byte aligned");
     Y5_REQUIRE(d.act == Y5_ACT_NONE || d.act == Y5_ACT_LEAKY, "conv: unknown activation %d", d.act);
+    Y5_REQUIRE(d.act == Y5_ACT_NONE || (d.slope > 0.f && d.slope <= 1.f), "conv: LeakyReLU slope %g outside (0, 1]", (double)d.slope);
 
     ConvArgs a;
     a.x = static_cast<const f16*>(d.x);
@@ -267,16 +348,33 @@ int y5_launch_conv(const y5_conv_desc& d, hipStream_t s) {
     a.M = (long long)d.batch * d.ho * d.wo;
     a.H = d.h; a.W = d.w_in; a.Cin = d.cin; a.x_ld = d.x_ld;
     a.Ho = d.ho; a.Wo = d.wo; a.Cout = d.cout; a.y_ld = d.y_ld; a.res_ld = d.res_ld;
-    a.stride = d.stride; a.pad = d.pad; a.K = d.ksize * d.ksize * d.cin; a.kpad = d.kpad;
+    a.stride = d.stride; a.pad = d.pad; a.K = d.ksize * d.ksize * d.cin;
+    a.w_ld = d.kpad; a.nk = 0;
     a.tiles_n = 0; a.tiles_total = 0;
-    a.act = d.act; a.slope = d.slope;
+    a.slope = d.act == Y5_ACT_LEAKY ? d.slope : 1.f;
+    a.div_hw = make_fastdiv((unsigned)(d.ho * d.wo));
+    a.div_wo = make_fastdiv((unsigned)d.wo);
+    a.div_cin = make_fastdiv((unsigned)d.cin);
+    const bool direct = d.ksize == 1 && d.stride == 1;
 
-    // Channel-tile width: the widest of {128, 64, 32} that wastes the fewest padded channels.
+    // Tile choice. Channel width: the widest of {128, 64, 32} that wastes the fewest padded channels.
+    // Pixel height: 128 rows unless that leaves the 256 CUs with fewer than ~4 workgroups each, in which
+    // case 64-row tiles double the number of independent DMA streams.  K-step: 64 (whole 128-byte lines per
+    // row) unless K is so short that rounding it up to 64 would mostly move padding.
     auto waste = [&](int bn) { return ((d.cout + bn - 1) / bn) * bn - d.cout; };
     int bn = 128;
     if (waste(64) < waste(bn)) bn = 64;
     if (waste(32) < waste(bn) && d.cout <= 32) bn = 32;
-    if (bn == 128) return launch_tile<128, 128, 2, 2>(a, d.ksize, s);
-    if (bn == 64) return launch_tile<128, 64, 2, 2>(a, d.ksize, s);
-    return launch_tile<128, 32, 4, 1>(a, d.ksize, s);
+    const long long blocks128 = ((a.M + 127) / 128) * ((d.cout + bn - 1) / bn);
+    const bool small = blocks128 < 1024;
+    const int tail = a.K % 64;
+    const bool k32 = a.K < 256 && tail != 0 && tail <= 32;
+    if (k32) {
+        if (bn == 128) return small ? launch_tile<64, 128, 2, 2, 4, 32>(a, d.ksize, direct, s) : launch_tile<128, 128, 2, 2, 3, 32>(a, d.ksize, direct, s);
+        if (bn == 64) return small ? launch_tile<64, 64, 2, 2, 4, 32>(a, d.ksize, direct, s) : launch_tile<128, 64, 2, 2, 4, 32>(a, d.ksize, direct, s);
+        return launch_tile<128, 32, 4, 1, 4, 32>(a, d.ksize, direct, s);
+    }
+    if (bn == 128) return small ? launch_tile<64, 128, 2, 2, 3, 64>(a, d.ksize, direct, s) : launch_tile<128, 128, 2, 2, 2, 64>(a, d.ksize, direct, s);
+    if (bn == 64) return small ? launch_tile<64, 64, 2, 2, 3, 64>(a, d.ksize, direct, s) : launch_tile<128, 64, 2, 2, 3, 64>(a, d.ksize, direct, s);
+    return launch_tile<128, 32, 4, 1, 3, 64>(a, d.ksize, direct, s);
 }

@@ -1,0 +1,69 @@
+"""Batch sharding over the GPUs of one node: one process per GPU, no per-layer collectives.
+
+Images are independent, weights are replicated, every rank runs conv -> decode -> NMS on its contiguous
+slice of the batch.  The only exchange is the final gather of the fixed-size detection blocks
+(det[B_local, max_det, 6] fp32 + count[B_local] int32, packed into one buffer) with a single all_gather
+over RCCL (backend "nccl" on ROCm) - or gloo on the CPU in tests.  The reference has no counterpart:
+its evaluation is single-GPU (test.py:74-76).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* when launched by
+    torch.distributed.run; returns (rank, world_size, local_rank). A plain single-process run returns (0, 1, 0)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_bounds(total, rank, world):
+    """Contiguous slice [lo, hi) of a batch of `total` images owned by `rank` (sizes differ by at most one)."""
+    base, extra = divmod(total, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def pack_detections(det, count):
+    """(B, max_det, 6) fp32 + (B,) int32 -> one (B, max_det*6 + 1) fp32 block (the count travels as raw bits)."""
+    B = det.shape[0]
+    block = torch.empty(B, det.shape[1] * 6 + 1, dtype=torch.float32, device=det.device)
+    block[:, :-1] = det.reshape(B, -1)
+    block[:, -1] = count.to(torch.int32).view(torch.float32)
+    return block
+
+
+def unpack_detections(block, max_det):
+    det = block[:, :-1].reshape(block.shape[0], max_det, 6)
+    count = block[:, -1].contiguous().view(torch.int32)
+    return det, count
+
+
+def gather_detections(det, count, group=None):
+    """All ranks contribute equally sized blocks; every rank receives (det_all, count_all) in global image order
+    (rank-major, which equals image order for contiguous shards)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return det, count
+    world = dist.get_world_size(group)
+    block = pack_detections(det, count)
+    out = torch.empty((world * block.shape[0], block.shape[1]), dtype=block.dtype, device=block.device)
+    dist.all_gather_into_tensor(out, block, group=group)
+    return unpack_detections(out, det.shape[1])
+
+
+def to_list(det, count):
+    """Padded detections -> the reference's list[None | Tensor(n, 6)] (utils/utils.py:584,641)."""
+    counts = count.tolist()
+    return [det[b, :c].clone() if c > 0 else None for b, c in enumerate(counts)]

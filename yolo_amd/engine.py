@@ -176,7 +176,7 @@ class Plan:
         return out
 
     def _pack_weight(self, weight, segs):
-        """(Cout, Cin_logical, k, k) -> fp16 [rows128][kpad32], K index (r*k + q)*cin_pad + c following `segs`."""
+        """(Cout, Cin_logical, k, k) -> fp16 [rows128][kpad64], K index (r*k + q)*cin_pad + c following `segs`."""
         cout, cin, k, _ = weight.shape
         if cin != sum(c for c, _ in segs):
             raise Unsupported('conv expects %d input channels, tensor has %d' % (cin, sum(c for c, _ in segs)))
@@ -184,7 +184,7 @@ class Plan:
         w = weight.detach().to(torch.float16).permute(0, 2, 3, 1)  # (Cout, k, k, Cin)
         rows = (cout + 127) // 128 * 128
         kk = k * k * cin_pad
-        kpad = (kk + 31) // 32 * 32
+        kpad = (kk + 63) // 64 * 64
         packed = torch.zeros(rows, kpad, dtype=torch.float16, device=self.device)
         view = packed[:cout, :kk].view(cout, k, k, cin_pad)
         src = dst = 0
