@@ -99,6 +99,13 @@ int y5_pack_image_f16(const void* x_nchw, void* y_nhwc, int batch, int c, int h,
 int y5_maxpool_f16(const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c, int k,
                    y5_stream_t stream);
 
+/* All pooling levels of SPP in one launch: level l (0-based) is the k x k stride-1 max pool applied l+1 times,
+ * i.e. a single pool of size l*(k-1)+k because max pooling composes exactly; k = 5 with 3 levels gives the
+ * reference's (5, 9, 13).  Replaces: the nn.MaxPool2d list of SPP  models/common.py:72,76.  Level l is written
+ * to channels [l*y_step, l*y_step + c) of y.  The h*w plane must fit in LDS (h*w*32 bytes <= 64 KiB). */
+int y5_maxpool_cascade_f16(const void* x, int x_ld, void* y, int y_ld, int y_step, int levels, int batch, int h, int w,
+                           int c, int k, y5_stream_t stream);
+
 /* 2x spatial upsampling of a channel slice into another (usually a concat) buffer.
  * Replaces: nn.Upsample(None, 2, 'nearest' | 'bilinear') + Concat  models/yolov5s.yaml:30-31,
  * models/yolov5s_ori.yaml:79-80.  mode 0 = nearest, 1 = bilinear with align_corners=False. */
@@ -197,6 +204,8 @@ int y5_plan_add_pack_image(y5_plan* p, const void* x_nchw, void* y_nhwc, int bat
                            int y_ld);
 int y5_plan_add_maxpool(y5_plan* p, const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c,
                         int k);
+int y5_plan_add_maxpool_cascade(y5_plan* p, const void* x, int x_ld, void* y, int y_ld, int y_step, int levels, int batch,
+                                int h, int w, int c, int k);
 int y5_plan_add_upsample2x(y5_plan* p, const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c,
                            int mode);
 int y5_plan_add_copy_channels(y5_plan* p, const void* x, int x_ld, void* y, int y_ld, int64_t pixels, int c);
@@ -214,6 +223,7 @@ int y5_plan_profile(y5_plan* p, void* const* ext, int n_ext, y5_stream_t stream,
 #define Y5_OP_UPSAMPLE 4
 #define Y5_OP_COPY 5
 #define Y5_OP_DECODE 6
+#define Y5_OP_MAXPOOL_CASCADE 7
 int y5_plan_op_info(const y5_plan* p, int i, int* kind, double* flops, double* bytes);
 
 #ifdef __cplusplus

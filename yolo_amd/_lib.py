@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, 'liby5hip.so')
 
 Y5_MAX_ANCHORS = 8
 ACT_NONE, ACT_LEAKY = 0, 1
-OP_NAMES = {1: 'conv', 2: 'pack', 3: 'maxpool', 4: 'upsample', 5: 'copy', 6: 'decode'}
+OP_NAMES = {1: 'conv', 2: 'pack', 3: 'maxpool', 4: 'upsample', 5: 'copy', 6: 'decode', 7: 'maxpool'}
 
 
 class ConvDesc(C.Structure):
@@ -48,6 +48,7 @@ SIGNATURES = {
     'y5_conv_f16': (_i, [C.POINTER(ConvDesc), _s]),
     'y5_pack_image_f16': (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _s]),
     'y5_maxpool_f16': (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _s]),
+    'y5_maxpool_cascade_f16': (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _s]),
     'y5_upsample2x_f16': (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _s]),
     'y5_copy_channels_f16': (_i, [_p, _i, _p, _i, C.c_int64, _i, _s]),
     'y5_detect_decode_f16': (_i, [C.POINTER(DecodeDesc), _s]),
@@ -60,6 +61,7 @@ SIGNATURES = {
     'y5_plan_add_conv': (_i, [_p, C.POINTER(ConvDesc)]),
     'y5_plan_add_pack_image': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i]),
     'y5_plan_add_maxpool': (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _i]),
+    'y5_plan_add_maxpool_cascade': (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i]),
     'y5_plan_add_upsample2x': (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _i]),
     'y5_plan_add_copy_channels': (_i, [_p, _p, _i, _p, _i, C.c_int64, _i]),
     'y5_plan_add_decode': (_i, [_p, C.POINTER(DecodeDesc)]),

@@ -48,6 +48,10 @@ extern "C" int y5_maxpool_f16(const void* x, int x_ld, void* y, int y_ld, int ba
                               y5_stream_t stream) {
     return y5_launch_maxpool(x, x_ld, y, y_ld, batch, h, w, c, k, static_cast<hipStream_t>(stream));
 }
+extern "C" int y5_maxpool_cascade_f16(const void* x, int x_ld, void* y, int y_ld, int y_step, int levels, int batch, int h, int w,
+                                      int c, int k, y5_stream_t stream) {
+    return y5_launch_maxpool_cascade(x, x_ld, y, y_ld, y_step, levels, batch, h, w, c, k, static_cast<hipStream_t>(stream));
+}
 extern "C" int y5_upsample2x_f16(const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c, int mode,
                                  y5_stream_t stream) {
     return y5_launch_upsample2x(x, x_ld, y, y_ld, batch, h, w, c, mode, static_cast<hipStream_t>(stream));
@@ -140,6 +144,8 @@ int run_op(const Op& op, hipStream_t s) {
         case Y5_OP_CONV: return y5_launch_conv(op.conv, s);
         case Y5_OP_PACK: return y5_launch_pack_image(op.px, op.py, op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], s);
         case Y5_OP_MAXPOOL: return y5_launch_maxpool(op.px, op.i[0], op.py, op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6], s);
+        case Y5_OP_MAXPOOL_CASCADE:
+            return y5_launch_maxpool_cascade(op.px, op.i[0], op.py, op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6], op.i[7], (int)op.pixels, s);
         case Y5_OP_UPSAMPLE: return y5_launch_upsample2x(op.px, op.i[0], op.py, op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6], s);
         case Y5_OP_COPY: return y5_launch_copy_channels(op.px, op.i[0], op.py, op.i[1], op.pixels, op.i[2], s);
         case Y5_OP_DECODE: return y5_launch_decode(op.dec, s);
@@ -236,6 +242,13 @@ extern "C" int y5_plan_add_maxpool(y5_plan* p, const void* x, int x_ld, void* y,
     Y5_REQUIRE(p, "plan_add_maxpool: null plan");
     const int iv[7] = {x_ld, y_ld, batch, h, w, c, k};
     return add_pointwise(p, Y5_OP_MAXPOOL, x, y, iv, 7, 0, 4.0 * batch * h * w * c);
+}
+
+extern "C" int y5_plan_add_maxpool_cascade(y5_plan* p, const void* x, int x_ld, void* y, int y_ld, int y_step, int levels, int batch,
+                                           int h, int w, int c, int k) {
+    Y5_REQUIRE(p, "plan_add_maxpool_cascade: null plan");
+    const int iv[8] = {x_ld, y_ld, y_step, levels, batch, h, w, c};
+    return add_pointwise(p, Y5_OP_MAXPOOL_CASCADE, x, y, iv, 8, k, 2.0 * batch * h * w * c * (1 + levels));
 }
 
 extern "C" int y5_plan_add_upsample2x(y5_plan* p, const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c, int mode) {

@@ -1,5 +1,6 @@
 // Batched non-maximum suppression for gfx950, three kernels per call and no host round trip:
-//   1. candidates: confidence filter + multi-label expansion with wavefront-ballot compaction.
+//   1. candidates: confidence filter + multi-label expansion.  Rows are staged through LDS with 16-byte
+//      loads, survivors are compacted with a wave scan and one atomic add per workgroup.
 //      Every surviving (anchor row, class) pair becomes one 64-bit sort key
 //      [descending-score bits | anchor_row*nc + class]; the slot order in the key buffer is
 //      irrelevant because the key itself carries the reference's tie order (lower index first).
@@ -42,49 +43,89 @@ __device__ __forceinline__ float ldf(const float* p) { return *p; }
 // ------------------------------------------------------------------------------------------
 // 1. candidates
 // ------------------------------------------------------------------------------------------
+// One workgroup stages CAND_ROWS consecutive prediction rows in LDS with 16-byte loads (the rows are contiguous
+// in memory), then every thread scores a strided share of the (row, class) pairs from LDS, remembers the
+// survivors in a bit mask, the workgroup reserves key slots with ONE atomic add, and the survivors are written.
+constexpr int CAND_ROWS = 64;
+constexpr int CAND_THREADS = 256;
+
 template <typename T>
-__global__ __launch_bounds__(256) void nms_candidates_kernel(const T* __restrict__ pred, int n_rows, int no, float conf_thres,
-                                                             const uint8_t* __restrict__ class_keep, u64* __restrict__ keys,
-                                                             int cap, int* __restrict__ counters) {
+__global__ __launch_bounds__(CAND_THREADS) void nms_candidates_kernel(const T* __restrict__ pred, int n_rows, int no, float conf_thres,
+                                                                      const uint8_t* __restrict__ class_keep, u64* __restrict__ keys,
+                                                                      int cap, int* __restrict__ counters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* tile = reinterpret_cast<T*>(smem_raw);
+    __shared__ int wave_total[CAND_THREADS / 64];
+    __shared__ int block_base;
+
     const int b = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nc = no - 5;
-    const int row_base = (blockIdx.x * 4 + wave) * 64;
-    if (row_base >= n_rows) return;
-    const int row = row_base + lane;
-    const T* img = pred + (long long)b * n_rows * no;
-    float obj = 0.f;
-    bool pass = false;
-    if (row < n_rows) {
-        obj = ldf(img + (long long)row * no + 4);
-        pass = obj > conf_thres;
+    const int r0 = blockIdx.x * CAND_ROWS;
+    const int nr = min(CAND_ROWS, n_rows - r0);
+    const T* src = pred + ((long long)b * n_rows + r0) * no;
+    const int total = nr * no;
+
+    // ---- stage the rows (flat copy)
+    constexpr int EPV = 16 / (int)sizeof(T);  // elements per 16-byte vector
+    if ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) {
+        const int nvec = total / EPV;
+        for (int i = tid; i < nvec; i += CAND_THREADS) reinterpret_cast<uint4*>(tile)[i] = reinterpret_cast<const uint4*>(src)[i];
+        for (int i = nvec * EPV + tid; i < total; i += CAND_THREADS) tile[i] = src[i];
+    } else {
+        for (int i = tid; i < total; i += CAND_THREADS) tile[i] = src[i];
     }
-    u64 rows_mask = __ballot(pass);
+    __syncthreads();
+
     u64* out = keys + (long long)b * cap;
-    while (rows_mask) {
-        const int src = __builtin_ctzll(rows_mask);
-        rows_mask &= rows_mask - 1;
-        const int r = row_base + src;
-        const float obj_r = __shfl(obj, src);
-        const T* rowp = img + (long long)r * no + 5;
-        for (int c0 = 0; c0 < nc; c0 += 64) {
-            const int c = c0 + lane;
-            bool ok = false;
-            float conf = 0.f;
-            if (c < nc) {
-                conf = ldf(rowp + c) * obj_r;  // conf = cls * obj in fp32
-                ok = conf > conf_thres && (!class_keep || class_keep[c]);
-            }
-            const u64 m = __ballot(ok);
-            if (m) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&counters[b], __builtin_popcountll(m));
-                base = __shfl(base, 0);
-                const int pos = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-                if (ok && pos < cap) out[pos] = ((u64)score_desc_bits(conf) << 32) | (unsigned)(r * nc + c);
+    const int pairs = nr * nc;
+    for (int chunk = 0; chunk < pairs; chunk += CAND_THREADS * 32) {
+        // ---- pass 1: which of this thread's pairs survive
+        unsigned mask = 0;
+#pragma unroll 4
+        for (int i = 0; i < 32; ++i) {
+            const int e = chunk + tid + i * CAND_THREADS;
+            if (e < pairs) {
+                const int row = e / nc, c = e - row * nc;
+                const float obj = ldf(tile + row * no + 4);
+                if (obj > conf_thres) {
+                    const float conf = ldf(tile + row * no + 5 + c) * obj;  // conf = cls * obj in fp32
+                    if (conf > conf_thres && (!class_keep || class_keep[c])) mask |= 1u << i;
+                }
             }
         }
+        // ---- workgroup-wide exclusive scan of the survivor counts, one atomic per workgroup
+        const int cnt = __builtin_popcount(mask);
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
+        }
+        if (lane == 63) wave_total[wave] = incl;
+        __syncthreads();
+        if (tid == 0) {
+            int sum = 0;
+            for (int w = 0; w < CAND_THREADS / 64; ++w) {
+                const int v = wave_total[w];
+                wave_total[w] = sum;
+                sum += v;
+            }
+            block_base = sum ? atomicAdd(&counters[b], sum) : 0;
+        }
+        __syncthreads();
+        int pos = block_base + wave_total[wave] + incl - cnt;
+        // ---- pass 2: write the keys
+        while (mask) {
+            const int i = __builtin_ctz(mask);
+            mask &= mask - 1;
+            const int e = chunk + tid + i * CAND_THREADS;
+            const int row = e / nc, c = e - row * nc;
+            const float conf = ldf(tile + row * no + 5 + c) * ldf(tile + row * no + 4);
+            if (pos < cap) out[pos] = ((u64)score_desc_bits(conf) << 32) | (unsigned)((r0 + row) * nc + c);
+            ++pos;
+        }
+        __syncthreads();  // wave_total / block_base are reused by the next chunk
     }
 }
 
@@ -359,13 +400,15 @@ extern "C" int y5_nms_batched(const y5_nms_desc* d, y5_stream_t stream) {
     const int cap_pow2 = pow2_at_least(d->max_candidates);
 
     Y5_HIP(hipMemsetAsync(counters, 0, counters_bytes, s));
-    const dim3 cgrid((unsigned)((d->n_rows + 255) / 256), (unsigned)d->batch);
+    const dim3 cgrid((unsigned)((d->n_rows + CAND_ROWS - 1) / CAND_ROWS), (unsigned)d->batch);
+    const size_t tile_bytes = ((size_t)CAND_ROWS * d->no * (d->pred_dtype == 0 ? 2 : 4) + 15) / 16 * 16;
+    Y5_REQUIRE(tile_bytes <= 60 * 1024, "nms: %d values per row do not fit the staging tile", d->no);
     if (d->pred_dtype == 0)
-        hipLaunchKernelGGL(nms_candidates_kernel<f16>, cgrid, dim3(256), 0, s, static_cast<const f16*>(d->pred), d->n_rows, d->no,
-                           d->conf_thres, d->class_keep, keys, cap_pow2, counters);
+        hipLaunchKernelGGL(nms_candidates_kernel<f16>, cgrid, dim3(CAND_THREADS), tile_bytes, s, static_cast<const f16*>(d->pred),
+                           d->n_rows, d->no, d->conf_thres, d->class_keep, keys, cap_pow2, counters);
     else
-        hipLaunchKernelGGL(nms_candidates_kernel<float>, cgrid, dim3(256), 0, s, static_cast<const float*>(d->pred), d->n_rows,
-                           d->no, d->conf_thres, d->class_keep, keys, cap_pow2, counters);
+        hipLaunchKernelGGL(nms_candidates_kernel<float>, cgrid, dim3(CAND_THREADS), tile_bytes, s, static_cast<const float*>(d->pred),
+                           d->n_rows, d->no, d->conf_thres, d->class_keep, keys, cap_pow2, counters);
     Y5_LAUNCH_CHECK("nms_candidates_kernel");
 
     hipLaunchKernelGGL(nms_sort_kernel, dim3((unsigned)d->batch), dim3(SORT_THREADS), SORT_LDS_KEYS * sizeof(u64), s, keys, cap_pow2,

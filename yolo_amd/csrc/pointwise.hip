@@ -114,6 +114,37 @@ __global__ __launch_bounds__(kThreads) void upsample2x_kernel(const f16* __restr
     }
 }
 
+// SPP in one launch: level l (l = 0..levels-1) is the k x k stride-1 max pool applied l+1 times, which equals
+// a single pool of size l*(k-1)+k (max composes exactly).  One workgroup owns one image and one 8-channel vector:
+// the H x W plane lives in LDS (two buffers), every level is read from LDS and written to LDS + global.
+__global__ __launch_bounds__(kThreads) void maxpool_cascade_kernel(const f16* __restrict__ x, int x_ld, f16* __restrict__ y, int y_ld,
+                                                                   int y_step, int levels, int H, int W, int C8, int k) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    f16x8* buf0 = reinterpret_cast<f16x8*>(smem_raw);
+    f16x8* buf1 = buf0 + H * W;
+    const int b = blockIdx.x / C8, c8 = blockIdx.x - b * C8;
+    const int npix = H * W, r = k / 2;
+    const long long pbase = (long long)b * npix;
+    for (int p = threadIdx.x; p < npix; p += kThreads) buf0[p] = *reinterpret_cast<const f16x8*>(x + (pbase + p) * x_ld + c8 * 8);
+    __syncthreads();
+    f16x8* src = buf0;
+    f16x8* dst = buf1;
+    for (int l = 0; l < levels; ++l) {
+        for (int p = threadIdx.x; p < npix; p += kThreads) {
+            const int py = p / W, px = p - py * W;
+            const int y0 = py - r < 0 ? 0 : py - r, y1 = py + r >= H ? H - 1 : py + r;
+            const int x0 = px - r < 0 ? 0 : px - r, x1 = px + r >= W ? W - 1 : px + r;
+            f16x8 m = src[y0 * W + x0];
+            for (int yy = y0; yy <= y1; ++yy)
+                for (int xx = x0; xx <= x1; ++xx) m = __builtin_elementwise_max(m, src[yy * W + xx]);
+            dst[p] = m;
+            *reinterpret_cast<f16x8*>(y + (pbase + p) * y_ld + (long long)l * y_step + c8 * 8) = m;
+        }
+        __syncthreads();
+        f16x8* t = src; src = dst; dst = t;
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void copy_channels_kernel(const f16* __restrict__ x, int x_ld, f16* __restrict__ y, int y_ld,
                                                                  long long pixels, int C8) {
     const long long total = pixels * C8;
@@ -174,5 +205,22 @@ int y5_launch_copy_channels(const void* x, int x_ld, void* y, int y_ld, int64_t 
     hipLaunchKernelGGL(copy_channels_kernel, dim3(grid_for(pixels * (c / 8))), dim3(kThreads), 0, s,
                        static_cast<const f16*>(x), x_ld, static_cast<f16*>(y), y_ld, (long long)pixels, c / 8);
     Y5_LAUNCH_CHECK("copy_channels_kernel");
+    return Y5_OK;
+}
+
+int y5_launch_maxpool_cascade(const void* x, int x_ld, void* y, int y_ld, int y_step, int levels, int batch, int h, int w, int c,
+                              int k, hipStream_t s) {
+    Y5_REQUIRE(x && y, "maxpool_cascade: null pointer");
+    Y5_REQUIRE(k % 2 == 1 && k >= 1 && k <= 13, "maxpool_cascade: k %d must be odd and <= 13", k);
+    Y5_REQUIRE(levels >= 1 && levels <= 8, "maxpool_cascade: levels %d out of range 1..8", levels);
+    Y5_REQUIRE(c > 0 && c % 8 == 0 && x_ld % 8 == 0 && y_ld % 8 == 0 && y_step % 8 == 0 && x_ld >= c && y_step >= c, "maxpool_cascade: channels/pitches must be multiples of 8");
+    Y5_REQUIRE((long long)(levels - 1) * y_step + c <= y_ld, "maxpool_cascade: levels do not fit the output pitch");
+    Y5_REQUIRE(batch > 0 && h > 0 && w > 0, "maxpool_cascade: empty tensor");
+    Y5_REQUIRE(y5_aligned16(x) && y5_aligned16(y), "maxpool_cascade: pointers must be 16-byte aligned");
+    const size_t lds = (size_t)2 * h * w * 16;
+    Y5_REQUIRE(lds <= 64 * 1024, "maxpool_cascade: %dx%d plane does not fit in LDS", h, w);
+    hipLaunchKernelGGL(maxpool_cascade_kernel, dim3((unsigned)(batch * (c / 8))), dim3(kThreads), lds, s, static_cast<const f16*>(x),
+                       x_ld, static_cast<f16*>(y), y_ld, y_step, levels, h, w, c / 8, k);
+    Y5_LAUNCH_CHECK("maxpool_cascade_kernel");
     return Y5_OK;
 }

@@ -40,6 +40,8 @@ static inline bool y5_aligned16(const void* p) { return (reinterpret_cast<uintpt
 int y5_launch_conv(const y5_conv_desc& d, hipStream_t s);
 int y5_launch_pack_image(const void* x, void* y, int batch, int c, int h, int w, int focus, int y_ld, hipStream_t s);
 int y5_launch_maxpool(const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c, int k, hipStream_t s);
+int y5_launch_maxpool_cascade(const void* x, int x_ld, void* y, int y_ld, int y_step, int levels, int batch, int h, int w, int c,
+                              int k, hipStream_t s);
 int y5_launch_upsample2x(const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c, int mode,
                          hipStream_t s);
 int y5_launch_copy_channels(const void* x, int x_ld, void* y, int y_ld, int64_t pixels, int c, hipStream_t s);

@@ -175,48 +175,55 @@ class Plan:
         self.keep.append(out)
         return out
 
-    def _pack_weight(self, weight, segs):
-        """(Cout, Cin_logical, k, k) -> fp16 [rows128][kpad64], K index (r*k + q)*cin_pad + c following `segs`."""
-        cout, cin, k, _ = weight.shape
-        if cin != sum(c for c, _ in segs):
-            raise Unsupported('conv expects %d input channels, tensor has %d' % (cin, sum(c for c, _ in segs)))
+    def _pack_weight(self, weights, segs):
+        """Row groups [(weight (c, Cin_logical, k, k), padded rows)] -> fp16 [rows128][kpad64];
+        K index (r*k + q)*cin_pad + c following the input tensor's channel `segs`."""
+        k = weights[0][0].shape[-1]
         cin_pad = sum(p for _, p in segs)
-        w = weight.detach().to(torch.float16).permute(0, 2, 3, 1)  # (Cout, k, k, Cin)
-        rows = (cout + 127) // 128 * 128
+        cin_log = sum(c for c, _ in segs)
+        total_rows = sum(p for _, p in weights)
+        rows = (total_rows + 127) // 128 * 128
         kk = k * k * cin_pad
         kpad = (kk + 63) // 64 * 64
         packed = torch.zeros(rows, kpad, dtype=torch.float16, device=self.device)
-        view = packed[:cout, :kk].view(cout, k, k, cin_pad)
-        src = dst = 0
-        for c, p in segs:
-            view[..., dst:dst + c] = w[..., src:src + c]
-            src += c
-            dst += p
+        r0 = 0
+        for weight, rpad in weights:
+            cout, cin = weight.shape[:2]
+            if cin != cin_log or weight.shape[-1] != k:
+                raise Unsupported('conv expects %d input channels, tensor has %d' % (cin, cin_log))
+            w = weight.detach().to(torch.float16).permute(0, 2, 3, 1)  # (Cout, k, k, Cin)
+            view = packed[r0:r0 + cout, :kk].view(cout, k, k, cin_pad)
+            src = dst = 0
+            for c, pc in segs:
+                view[..., dst:dst + c] = w[..., src:src + c]
+                src += c
+                dst += pc
+            r0 += rpad
         self.keep.append(packed)
         return packed, kpad, rows
 
     # ------------------------------------------------------------------ op emitters
-    def _conv(self, label, x, conv, out, bias=None, affine=None, act=None, res=None):
-        """Record one convolution. conv: nn.Conv2d; out: Act slice to write; affine: (scale, shift) tensors."""
-        k, s = _conv_geometry(conv)
-        if conv.weight.dtype is not torch.float16 or conv.weight.device != self.device:
-            raise Unsupported('conv weights must be fp16 on the input device')
-        cout = conv.out_channels
-        if out.c_log != cout or len(out.segs) != 1:
+    def _emit_conv(self, label, x, weights, k, s, out, bias=None, scale=None, shift=None, slope=None, res=None):
+        """Record one convolution. weights: row groups [(tensor, padded rows)] matching out.segs; out: Act slice to
+        write; bias/scale/shift: fp32 vectors of out.c_pad entries (or None); slope: LeakyReLU slope or None."""
+        for w, _ in weights:
+            if w.dtype is not torch.float16 or w.device != self.device:
+                raise Unsupported('conv weights must be fp16 on the input device')
+        if [p for _, p in weights] != [p for _, p in out.segs] or [w.shape[0] for w, _ in weights] != [c for c, _ in out.segs]:
             raise Unsupported('conv output slice mismatch')
         ho = (x.h + 2 * (k // 2) - k) // s + 1
         wo = (x.w + 2 * (k // 2) - k) // s + 1
         if (ho, wo) != (out.h, out.w):
             raise Unsupported('conv output size mismatch')
-        packed, kpad, rows = self._pack_weight(conv.weight, x.segs)
+        packed, kpad, rows = self._pack_weight(weights, x.segs)
         d = _lib.ConvDesc()
         d.x, d.w, d.y = x.ptr, packed.data_ptr(), out.ptr
         cpad = out.c_pad
         if bias is not None:
             d.bias = self._f32(bias, cpad).data_ptr()
-        if affine is not None:
-            d.scale = self._f32(affine[0], cpad).data_ptr()
-            d.shift = self._f32(affine[1], cpad).data_ptr()
+        if scale is not None:
+            d.scale = self._f32(scale, cpad).data_ptr()
+            d.shift = self._f32(shift, cpad).data_ptr()
         if res is not None:
             if (res.c_pad, res.h, res.w) != (cpad, ho, wo):
                 raise Unsupported('residual shape mismatch')
@@ -225,14 +232,31 @@ class Plan:
         d.ho, d.wo, d.cout, d.y_ld = ho, wo, cpad, out.ld
         d.ksize, d.stride, d.pad = k, s, k // 2
         d.kpad, d.w_rows = kpad, rows
-        if act is None or isinstance(act, nn.Identity):
+        if slope is None:
             d.act, d.slope = _lib.ACT_NONE, 0.0
-        elif isinstance(act, nn.LeakyReLU):
-            d.act, d.slope = _lib.ACT_LEAKY, float(act.negative_slope)
         else:
-            raise Unsupported('activation %s' % type(act).__name__)
+            if not 0.0 < slope <= 1.0:
+                raise Unsupported('LeakyReLU slope %g' % slope)
+            d.act, d.slope = _lib.ACT_LEAKY, slope
         _lib.check(self.lib.y5_plan_add_conv(self.handle, C.byref(d)))
-        self.labels.append('%s conv%dx%d s%d %d->%d @%dx%d' % (label, k, k, s, x.c_log, cout, ho, wo))
+        self.labels.append('%s conv%dx%d s%d %d->%d @%dx%d' % (label, k, k, s, x.c_log, out.c_log, ho, wo))
+
+    @staticmethod
+    def _slope(act):
+        if act is None or isinstance(act, nn.Identity):
+            return None
+        if isinstance(act, nn.LeakyReLU):
+            return float(act.negative_slope)
+        raise Unsupported('activation %s' % type(act).__name__)
+
+    def _conv(self, label, x, conv, out, bias=None, affine=None, act=None, res=None):
+        """One nn.Conv2d with optional bias, folded BatchNorm (scale, shift) and activation module."""
+        k, s = _conv_geometry(conv)
+        if len(out.segs) != 1:
+            raise Unsupported('conv output slice mismatch')
+        self._emit_conv(label, x, [(conv.weight, out.segs[0][1])], k, s, out, bias=bias,
+                        scale=None if affine is None else affine[0], shift=None if affine is None else affine[1],
+                        slope=self._slope(act), res=res)
 
     def _conv_block(self, label, m, x, out, res=None):
         """A models.common.Conv (conv + BatchNorm + activation, or its fused form)."""
@@ -432,29 +456,59 @@ class Plan:
         self._conv_block(name + '.cv2', m.cv2, hidden, out, res=x if m.add else None)
 
     def _csp(self, name, m, x, out):
-        """BottleneckCSP (models/common.py:59-62): the BatchNorm + LeakyReLU that act on cat(y1, y2) are split per
-        half and folded into the epilogues of cv3 and cv2, which write straight into the concat buffer."""
+        """BottleneckCSP (models/common.py:59-62).  cv1 (Conv) and cv2 (plain 1x1) read the same input, so they run
+        as ONE convolution whose output rows are [cv1 | cv2]: buffer U = [t | y2].  The BatchNorm + LeakyReLU that
+        the reference applies to cat(y1, y2) is split per half: its second half is the epilogue of the cv2 rows, its
+        first half the epilogue of cv3, which writes y1 over t's slot once the bottlenecks are done with t - so U
+        becomes cat(y1, y2) without a copy and cv4 reads it directly."""
         if m.cv2.bias is not None or m.cv3.bias is not None:
             raise Unsupported('CSP plain convs with bias')
-        c1 = m.cv1.conv.out_channels
-        t = self._new_act(x.batch, x.h, x.w, [(c1, pad8(c1))])
-        self._conv_block(name + '.cv1', m.cv1, x, t)
+        c1, c2, c3 = m.cv1.conv.out_channels, m.cv2.out_channels, m.cv3.out_channels
+        if m.bn.num_features != c3 + c2:
+            raise Unsupported('CSP BatchNorm width')
+        scale, shift = bn_affine(m.bn)
+        slope = self._slope(m.act)
+        fuse = (pad8(c1) == pad8(c3) and len(m.m) > 0 and self._slope(m.cv1.act) == slope and slope is not None
+                and _conv_geometry(m.cv1.conv) == (1, 1) and _conv_geometry(m.cv2) == (1, 1))
+        if fuse:
+            p1, p2 = pad8(c1), pad8(c2)
+            U = self._new_act(x.batch, x.h, x.w, [(c1, p1), (c2, p2)])
+            dev = self.device
+            one, zero = torch.ones(p1, device=dev), torch.zeros(p1, device=dev)
+            if m.cv1.bn is None:   # cv1 already carries its folded bias; identity affine on its rows
+                b1 = torch.zeros(p1, device=dev)
+                b1[:c1] = m.cv1.conv.bias.detach().float()
+                sc1, sh1 = one, zero
+            else:
+                if m.cv1.conv.bias is not None:
+                    raise Unsupported('unfused Conv with conv bias')
+                b1 = zero
+                s1, h1 = bn_affine(m.cv1.bn)
+                sc1, sh1 = one.clone(), zero.clone()
+                sc1[:c1], sh1[:c1] = s1, h1
+            sc2, sh2 = torch.zeros(p2, device=dev), torch.zeros(p2, device=dev)
+            sc2[:c2], sh2[:c2] = scale[c3:], shift[c3:]
+            self._emit_conv(name + '.cv1+cv2', x, [(m.cv1.conv.weight, p1), (m.cv2.weight, p2)], 1, 1, U,
+                            bias=torch.cat((b1, torch.zeros(p2, device=dev))), scale=torch.cat((sc1, sc2)),
+                            shift=torch.cat((sh1, sh2)), slope=slope)
+            t = U.slice(0, [(c1, p1)])
+            cat = Act(U.buf, U.off, U.ld, U.batch, U.h, U.w, [(c3, pad8(c3)), (c2, p2)])
+        else:
+            t = self._new_act(x.batch, x.h, x.w, [(c1, pad8(c1))])
+            self._conv_block(name + '.cv1', m.cv1, x, t)
+            cat = self._new_act(x.batch, x.h, x.w, [(c3, pad8(c3)), (c2, pad8(c2))])
+            self._conv(name + '.cv2', x, m.cv2, cat.slice(pad8(c3), [(c2, pad8(c2))]), affine=(scale[c3:], shift[c3:]), act=m.act)
         for bi, b in enumerate(m.m):
             nxt = self._new_act(x.batch, x.h, x.w, [(b.cv2.conv.out_channels, pad8(b.cv2.conv.out_channels))])
             self._bottleneck('%s.m%d' % (name, bi), b, t, nxt)
             t = nxt
-        c3, c2 = m.cv3.out_channels, m.cv2.out_channels
-        if m.bn.num_features != c3 + c2:
-            raise Unsupported('CSP BatchNorm width')
-        cat = self._new_act(x.batch, x.h, x.w, [(c3, pad8(c3)), (c2, pad8(c2))])
-        scale, shift = bn_affine(m.bn)
         self._conv(name + '.cv3', t, m.cv3, cat.slice(0, [(c3, pad8(c3))]), affine=(scale[:c3], shift[:c3]), act=m.act)
-        self._conv(name + '.cv2', x, m.cv2, cat.slice(pad8(c3), [(c2, pad8(c2))]), affine=(scale[c3:], shift[c3:]), act=m.act)
         self._conv_block(name + '.cv4', m.cv4, cat, out)
 
     def _spp(self, name, m, x, out):
-        """SPP (models/common.py:74-76). Pool sizes (5, 9, 13) are evaluated as a cascade of 5x5 pools, which is
-        exact for max; other size lists run each pool directly."""
+        """SPP (models/common.py:74-76). Pool sizes of the form (k, 2k-1, 3k-2, ...) such as (5, 9, 13) are evaluated
+        as a cascade of k x k pools, which is exact for max - in one launch when the plane fits in LDS; other size
+        lists run each pool directly."""
         ks = [p.kernel_size if isinstance(p.kernel_size, int) else p.kernel_size[0] for p in m.m]
         for p, k in zip(m.m, ks):
             st = p.stride if isinstance(p.stride, int) else p.stride[0]
@@ -466,12 +520,19 @@ class Plan:
         cat = self._new_act(x.batch, x.h, x.w, seg * (len(ks) + 1))
         first = cat.slice(0, seg)
         self._conv_block(name + '.cv1', m.cv1, x, first)
-        cascade = ks == [5, 9, 13]
+        cascade = all(k == n * (ks[0] - 1) + ks[0] for n, k in enumerate(ks))
+        if cascade and x.h * x.w * 32 <= 64 * 1024 and len(ks) <= 8:
+            dst = cat.slice(pad8(c), seg)
+            _lib.check(self.lib.y5_plan_add_maxpool_cascade(self.handle, first.ptr, first.ld, dst.ptr, dst.ld, pad8(c), len(ks),
+                                                            x.batch, x.h, x.w, pad8(c), ks[0]))
+            self.labels.append('%s maxpool %s' % (name, 'x'.join(str(k) for k in ks)))
+            self._conv_block(name + '.cv2', m.cv2, cat, out)
+            return
         for n, k in enumerate(ks):
             src = cat.slice(n * pad8(c), seg) if cascade else first
             dst = cat.slice((n + 1) * pad8(c), seg)
             _lib.check(self.lib.y5_plan_add_maxpool(self.handle, src.ptr, src.ld, dst.ptr, dst.ld, x.batch, x.h, x.w, pad8(c),
-                                                    5 if cascade else k))
+                                                    ks[0] if cascade else k))
             self.labels.append('%s maxpool%d' % (name, k))
         self._conv_block(name + '.cv2', m.cv2, cat, out)
 
