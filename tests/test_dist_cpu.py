@@ -1,0 +1,70 @@
+"""Batch sharding + detection gather with two gloo ranks on the CPU (the N>1 path of bench.py / yolo_amd.dist)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import util
+from yolo_amd import dist as ydist
+from yolo_amd.utils import utils as yu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _pad(out, max_det=300):
+    det = torch.zeros(len(out), max_det, 6)
+    cnt = torch.zeros(len(out), dtype=torch.int32)
+    for b, o in enumerate(out):
+        if o is not None:
+            det[b, :o.shape[0]] = o
+            cnt[b] = o.shape[0]
+    return det, cnt
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    r, w, _ = ydist.init_from_env(backend='gloo')
+    z = util.golden('nms_multilabel')
+    pred = torch.from_numpy(np.concatenate([z['pred'], z['pred'][::-1]], 0))  # 4 images
+    lo, hi = ydist.shard_bounds(pred.shape[0], r, w)
+    det, cnt = _pad(yu.non_max_suppression(pred[lo:hi].clone(), float(z['conf']), float(z['iou'])))
+    det_all, cnt_all = ydist.gather_detections(det, cnt)
+    if r == 0:
+        q.put((det_all.numpy(), cnt_all.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_equals_single_process():
+    ctx = mp.get_context('spawn')
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    det_all, cnt_all = q.get()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    z = util.golden('nms_multilabel')
+    want_det = np.concatenate([z['det'], z['det'][::-1]], 0)
+    want_cnt = np.concatenate([z['count'], z['count'][::-1]], 0)
+    assert np.array_equal(cnt_all, want_cnt) and np.array_equal(det_all, want_det)
+    out = ydist.to_list(torch.from_numpy(det_all), torch.from_numpy(cnt_all))
+    assert len(out) == 4 and out[0].shape == (int(want_cnt[0]), 6)
+
+
+def test_shard_bounds_and_packing():
+    assert [ydist.shard_bounds(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert [ydist.shard_bounds(256, r, 8) for r in range(8)] == [(32 * r, 32 * r + 32) for r in range(8)]
+    det = torch.rand(3, 300, 6)
+    cnt = torch.tensor([0, 300, 17], dtype=torch.int32)
+    d2, c2 = ydist.unpack_detections(ydist.pack_detections(det, cnt), 300)
+    assert torch.equal(d2, det) and torch.equal(c2, cnt)

@@ -1,0 +1,194 @@
+"""Data-movement kernels, Detect decode and NMS through the C ABI: bit-exact against torch / golden / oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import util
+from oracle import nms_c, y5ref
+from yolo_amd import _lib, nms as hip_nms
+from yolo_amd.utils import utils as yu
+
+pytestmark = pytest.mark.gpu
+
+
+def nhwc(t, ld, dev):
+    B, Cc, H, W = t.shape
+    out = torch.zeros(B, H, W, ld, dtype=torch.float16, device=dev)
+    out[..., :Cc] = t.permute(0, 2, 3, 1)
+    return out
+
+
+@pytest.mark.parametrize('focus', [0, 1])
+def test_pack_image(dev, focus):
+    lib = _lib.lib()
+    x = torch.rand(3, 3, 32, 48, generator=torch.Generator().manual_seed(0)).half().to(dev)
+    ld = 16 if focus else 8
+    y = torch.full((3, 32 // (1 + focus), 48 // (1 + focus), ld), float('nan'), dtype=torch.float16, device=dev)
+    _lib.check(lib.y5_pack_image_f16(x.data_ptr(), y.data_ptr(), 3, 3, 32, 48, focus, ld, _lib.current_stream()))
+    ref = y5ref.focus_gather(x) if focus else x
+    assert torch.equal(y[..., :ref.shape[1]], ref.permute(0, 2, 3, 1)) and bool((y[..., ref.shape[1]:] == 0).all())
+
+
+@pytest.mark.parametrize('k', [5, 9, 13])
+def test_maxpool_and_cascade(dev, k):
+    lib = _lib.lib()
+    x = torch.randn(2, 16, 20, 14, generator=torch.Generator().manual_seed(k)).half().to(dev)
+    xn = nhwc(x, 16, dev)
+    y = torch.zeros_like(xn)
+    _lib.check(lib.y5_maxpool_f16(xn.data_ptr(), 16, y.data_ptr(), 16, 2, 20, 14, 16, k, _lib.current_stream()))
+    assert torch.equal(y.permute(0, 3, 1, 2), F.max_pool2d(x, k, 1, k // 2))
+    if k == 5:  # SPP in one launch, written into slices 1..3 of a 4-slice concat buffer
+        cat = torch.zeros(2, 20, 14, 64, dtype=torch.float16, device=dev)
+        cat[..., :16] = xn
+        _lib.check(lib.y5_maxpool_cascade_f16(cat.data_ptr(), 64, cat.data_ptr() + 32, 64, 16, 3, 2, 20, 14, 16, 5,
+                                               _lib.current_stream()))
+        ref = torch.cat([x] + [F.max_pool2d(x, kk, 1, kk // 2) for kk in (5, 9, 13)], 1)
+        assert torch.equal(cat.permute(0, 3, 1, 2), ref)
+
+
+@pytest.mark.parametrize('mode', ['nearest', 'bilinear'])
+def test_upsample_into_concat_slice(dev, mode):
+    lib = _lib.lib()
+    z = util.golden('block_upsample_%s_concat' % mode)
+    a, b = torch.from_numpy(z['a']).half().to(dev), torch.from_numpy(z['b']).half().to(dev)
+    an = nhwc(a, 16, dev)
+    cat = torch.zeros(2, 12, 10, 40, dtype=torch.float16, device=dev)
+    cat[..., 16:] = b.permute(0, 2, 3, 1)
+    _lib.check(lib.y5_upsample2x_f16(an.data_ptr(), 16, cat.data_ptr(), 40, 2, 6, 5, 16, 0 if mode == 'nearest' else 1,
+                                      _lib.current_stream()))
+    ref = torch.cat([F.interpolate(a.float(), scale_factor=2.0, mode=mode, **({} if mode == 'nearest' else {'align_corners': False})).half(), b], 1)
+    got = cat.permute(0, 3, 1, 2)
+    if mode == 'nearest':
+        assert torch.equal(got, ref)
+    else:  # fp32 blend rounded once: at most one fp16 ulp from torch's own kernel
+        assert float((got.float() - ref.float()).abs().max()) <= 2e-3 * float(ref.float().abs().max())
+
+
+def test_copy_channels(dev):
+    lib = _lib.lib()
+    src = torch.randn(50, 24, generator=torch.Generator().manual_seed(0)).half().to(dev)
+    dst = torch.zeros(50, 40, dtype=torch.float16, device=dev)
+    _lib.check(lib.y5_copy_channels_f16(src.data_ptr(), 24, dst.data_ptr() + 16, 40, 50, 24, _lib.current_stream()))
+    assert torch.equal(dst[:, 8:32], src) and bool((dst[:, :8] == 0).all()) and bool((dst[:, 32:] == 0).all())
+
+
+def decode_level(dev, raw, stride, anchors_wh, z_out, row0, no):
+    lib = _lib.lib()
+    B, c, ny, nx = raw.shape
+    na = c // no
+    ld = (c + 7) // 8 * 8
+    head = nhwc(raw, ld, dev)
+    xo = torch.zeros(B, na, ny, nx, no, dtype=torch.float16, device=dev)
+    d = _lib.DecodeDesc()
+    d.head, d.head_ld, d.x_out, d.z_out = head.data_ptr(), ld, xo.data_ptr(), z_out.data_ptr()
+    d.batch, d.ny, d.nx, d.na, d.no = B, ny, nx, na, no
+    d.z_rows_total, d.z_row0, d.stride = z_out.shape[1], row0, float(stride)
+    for a in range(na):
+        d.anchor_wh[2 * a], d.anchor_wh[2 * a + 1] = float(anchors_wh[a, 0]), float(anchors_wh[a, 1])
+    _lib.check(lib.y5_detect_decode_f16(C.byref(d), _lib.current_stream()))
+    torch.cuda.synchronize()
+    return xo
+
+
+@pytest.mark.parametrize('tag', ['nc80_64x96', 'nc5_128x128', 'nc1_odd'])
+def test_decode_bit_exact_against_reference_fixture(dev, tag):
+    z = util.golden('decode_' + tag)
+    zg = torch.from_numpy(z['z'])
+    zo = torch.zeros(zg.shape, dtype=torch.float16, device=dev)
+    row0 = 0
+    for i in range(3):
+        raw = torch.from_numpy(z['raw%d' % i]).to(dev)
+        xo = decode_level(dev, raw, z['stride'][i], z['anchor_grid'][i].reshape(-1, 2), zo, row0, zg.shape[2])
+        assert torch.equal(xo.cpu(), torch.from_numpy(z['x%d' % i]))
+        row0 += 3 * raw.shape[2] * raw.shape[3]
+    assert torch.equal(zo.cpu().view(torch.int16), zg.view(torch.int16))
+
+
+def test_decode_full_size_level_against_oracle(dev):
+    g = torch.Generator().manual_seed(0)
+    raw = (torch.randn(2, 255, 80, 80, generator=g) * 4).half()
+    ag = torch.tensor([10., 13, 16, 30, 33, 23]).view(1, 1, 3, 1, 1, 2)
+    zr, xr = y5ref.detect_decode([raw], ag, torch.tensor([8.]), True)
+    zo = torch.zeros(zr.shape, dtype=torch.float16, device=dev)
+    xo = decode_level(dev, raw.to(dev), 8.0, ag.view(3, 2), zo, 0, 85)
+    assert torch.equal(xo.cpu(), xr[0]) and torch.equal(zo.cpu().view(torch.int16), zr.view(torch.int16))
+
+
+NMS_CASES = ['multilabel', 'conf01', 'ties', 'agnostic', 'classes', 'over300', 'nc1', 'empty', 'half_input', 'single']
+
+
+@pytest.mark.parametrize('name', NMS_CASES)
+def test_nms_bit_exact_against_reference_fixture(dev, name):
+    z = util.golden('nms_' + name)
+    classes = list(z['classes']) if len(z['classes']) else None
+    pred = torch.from_numpy(z['pred']).to(dev)
+    det, cnt, kept, ncand = hip_nms.nms_padded(pred, float(z['conf']), float(z['iou']), classes=classes,
+                                               agnostic=bool(z['agnostic']), return_index=True)
+    assert np.array_equal(cnt.cpu().numpy(), z['count']) and np.array_equal(det.cpu().numpy(), z['det'])
+    ref = nms_c.non_max_suppression(z['pred'], float(z['conf']), float(z['iou']), classes=classes, agnostic=bool(z['agnostic']))
+    for b, (rdet, ridx, rn) in enumerate(ref):
+        assert int(ncand[b]) == rn and np.array_equal(kept[b, :len(ridx)].cpu().numpy(), ridx)
+        assert bool((kept[b, len(ridx):] == -1).all())
+    out = yu.non_max_suppression(pred, float(z['conf']), float(z['iou']), classes=classes, agnostic=bool(z['agnostic']))
+    for b, o in enumerate(out):
+        assert (o is None) == (z['count'][b] == 0)
+        if o is not None:
+            assert o.is_cuda and np.array_equal(o.cpu().numpy(), z['det'][b, :z['count'][b]])
+
+
+def synth_prediction(seed, B, N, nc, frac=0.05):
+    g = torch.Generator().manual_seed(seed)
+    cxy = torch.rand(B, N, 2, generator=g) * 640
+    wh = torch.exp(torch.randn(B, N, 2, generator=g) * 0.5 + 3.5)
+    obj = torch.rand(B, N, 1, generator=g) * (torch.rand(B, N, 1, generator=g) < frac)
+    cls = torch.rand(B, N, nc, generator=g) ** 3
+    return torch.cat((cxy, wh, obj, cls), 2)
+
+
+def test_nms_full_size_indices_equal_the_oracle(dev):
+    """25200 rows x 80 classes per image in fp16, conf 0.001 / iou 0.65 (the test.py setting): kept candidate
+    indices and rows must equal the C oracle's exactly; also exercises the capacity-retry path."""
+    pred = synth_prediction(3, 3, 25200, 80).half()
+    ref = nms_c.non_max_suppression(pred.numpy(), 0.001, 0.65)
+    det, cnt, kept, ncand = hip_nms.nms_padded(pred.to(dev), 0.001, 0.65, return_index=True, max_candidates=4096)
+    for b, (rdet, ridx, rn) in enumerate(ref):
+        assert rn > 4096 and int(ncand[b]) == rn and int(cnt[b]) == len(ridx) == 300
+        assert np.array_equal(kept[b, :300].cpu().numpy(), ridx) and np.array_equal(det[b, :300].cpu().numpy(), rdet)
+    scores = det[..., 4].cpu()
+    assert bool((scores[:, :-1] >= scores[:, 1:]).all())  # descending confidence
+
+
+def test_nms_large_candidate_sets_sort_through_global_memory(dev):
+    pred = synth_prediction(4, 1, 25200, 80, frac=0.3).half()   # > 16384 candidates: multi-block sort
+    ref = nms_c.non_max_suppression(pred.numpy(), 0.05, 0.5)
+    det, cnt, kept, ncand = hip_nms.nms_padded(pred.to(dev), 0.05, 0.5, return_index=True, max_candidates=1 << 20)
+    assert ref[0][2] > 16384 and int(ncand[0]) == ref[0][2]
+    assert np.array_equal(kept[0, :len(ref[0][1])].cpu().numpy(), ref[0][1])
+
+
+def test_box_nms_primitive_and_merge_path(dev):
+    g = torch.Generator().manual_seed(0)
+    xy = torch.rand(3000, 2, generator=g) * 300
+    boxes = torch.cat((xy, xy + torch.rand(3000, 2, generator=g) * 60 + 5), 1)
+    scores = (torch.randint(0, 100, (3000,), generator=g) / 100).float()
+    keep = hip_nms.nms(boxes.to(dev), scores.to(dev), 0.5, max_keep=1024).cpu().numpy()
+    assert np.array_equal(keep, nms_c.nms(boxes.numpy(), scores.numpy(), 0.5)[:1024])
+    assert hip_nms.nms(boxes[:0].to(dev), scores[:0].to(dev), 0.5).numel() == 0
+    z = util.golden('nms_merge')
+    out = yu.non_max_suppression(torch.from_numpy(z['pred']).to(dev), float(z['conf']), float(z['iou']), merge=True)
+    for b, o in enumerate(out):
+        assert o.shape[0] == z['count'][b]
+        assert np.allclose(o.cpu().numpy(), z['det'][b, :z['count'][b]], rtol=1e-4, atol=1e-3)
+
+
+def test_nms_is_idempotent_on_its_own_output(dev):
+    """Property: boxes that survived do not suppress each other, so feeding them back keeps all of them."""
+    pred = synth_prediction(5, 1, 5000, 4, frac=0.5).to(dev)
+    det, cnt = hip_nms.nms_padded(pred, 0.1, 0.5, agnostic=True)
+    n = int(cnt[0])
+    d = det[0, :n]
+    keep = hip_nms.nms(d[:, :4].contiguous(), d[:, 4].contiguous(), 0.5, max_keep=300)
+    assert keep.tolist() == list(range(n))

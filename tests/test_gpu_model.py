@@ -1,0 +1,134 @@
+"""Whole-graph HIP forward (Model.forward -> engine) + NMS against the oracle and against torch's own GPU kernels."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+import util
+from oracle import nms_c, y5ref
+from yolo_amd import engine
+from yolo_amd.utils.utils import non_max_suppression
+
+pytestmark = pytest.mark.gpu
+
+
+def calls(model):
+    eng = model.__dict__.get('_y5_engine')
+    return eng.calls if eng else 0
+
+
+def agree(got, ref, frac_exact, rel=4e-3):
+    """End-to-end fp16 outputs: elementwise |d| <= rel*|ref| + rel*max|ref| and a minimum share of identical values
+    (half-precision graphs are chaotic end to end, so the bound is looser than per layer)."""
+    got, ref = got.float().cpu(), ref.float().cpu()
+    d = (got - ref).abs()
+    assert bool((d <= rel * ref.abs() + rel * ref.abs().max()).all()), 'max |d| %g' % float(d.max())
+    assert float((d == 0).float().mean()) >= frac_exact
+
+
+@pytest.mark.parametrize('cfg,fuse,shape', [('yolov5s', False, (2, 3, 64, 64)), ('yolov5s', True, (1, 3, 128, 96)),
+                                            ('yolov5s_ori', False, (2, 3, 64, 64)), ('yolov5s_ori', True, (2, 3, 96, 160))])
+def test_forward_against_oracle(dev, cfg, fuse, shape):
+    model = util.build_model(cfg)
+    util.randomize_bn(model, 11)
+    model.eval()
+    if fuse:
+        util.quiet(model.fuse)
+    model = model.half().to(dev)
+    x = torch.rand(*shape, generator=torch.Generator().manual_seed(5)).half()
+    z, xs = model(x.to(dev))
+    assert calls(model) == 1, 'the forward must run on the HIP engine'
+    cfgd = yaml.safe_load(open(os.path.join(util.CFG_DIR, cfg + '.yaml')))
+    sd = {k: v.float().cpu() for k, v in model.state_dict().items()}
+    zr, xr = y5ref.forward(cfgd, sd, x.float(), precision='half', strides=model.stride)
+    assert z.shape == zr.shape and z.dtype is torch.float16
+    for a, b in zip(xs, xr):
+        assert a.shape == b.shape
+        agree(a, b, 0.75)
+    agree(z, zr, 0.95)
+    # torch's own GPU kernels on the same modules must agree with the oracle no better than the HIP path does
+    with engine.disabled():
+        zt, _ = model(x.to(dev))
+    assert calls(model) == 1
+    agree(z, zt, 0.90)
+
+
+def test_detections_match_oracle_on_engine_output(dev):
+    """forward -> non_max_suppression on the GPU; the NMS stage must reproduce the oracle exactly on the very
+    predictions the engine produced (kept boxes are bit-identical given identical scores)."""
+    model = util.build_model('yolov5s')
+    util.calibrate(model, size=256, head_gain=2.0)
+    model = util.quiet(model.fuse).eval().half().to(dev)
+    x = torch.rand(2, 3, 256, 256, generator=torch.Generator().manual_seed(1)).half().to(dev)
+    z, _ = model(x)
+    out = non_max_suppression(z, 0.001, 0.65)
+    ref = nms_c.non_max_suppression(z.cpu().numpy(), 0.001, 0.65)
+    assert any(r[2] > 300 for r in ref), 'the synthetic head should produce an NMS-heavy candidate load'
+    for o, (rdet, ridx, rn) in zip(out, ref):
+        assert o is not None and np.array_equal(o.cpu().numpy(), rdet)
+
+
+def test_pruned_channel_plan_runs_on_the_engine(dev):
+    """Irregular channel counts of a filter-pruned yolov5s_ori (shapes from the reference's filter_pruning):
+    every tensor is padded to a multiple of 8 channels inside the engine; results must match torch's kernels."""
+    model = util.prune_like(util.build_model('yolov5s_ori'))
+    util.randomize_bn(model, 3)
+    model = model.eval().half().to(dev)
+    x = torch.rand(2, 3, 96, 64, generator=torch.Generator().manual_seed(2)).half().to(dev)
+    z, xs = model(x)
+    assert calls(model) == 1
+    with engine.disabled():
+        zt, xt = model(x)
+    for a, b in zip(xs, xt):
+        agree(a, b, 0.70)
+    agree(z, zt, 0.90)
+
+
+def test_engine_steps_aside_for_hooks_grad_training_and_fp32(dev):
+    model = util.build_model('yolov5s').eval().half().to(dev)
+    x = torch.rand(1, 3, 64, 64).half().to(dev)
+    model(x)
+    assert calls(model) == 1
+    with torch.enable_grad():
+        model(x)
+    assert calls(model) == 1
+    h = model.model[1].conv.register_forward_hook(lambda m, i, o: None)
+    model(x)
+    assert calls(model) == 1
+    h.remove()
+    model(x)
+    assert calls(model) == 2
+    out = model.train()(x)
+    assert isinstance(out, list) and calls(model) == 2
+    model.eval()
+    model.model[-1].export = True
+    assert isinstance(model(x), list) and calls(model) == 2   # export mode returns the raw maps like training
+    model.model[-1].export = False
+    model.model[-1].training = False
+    model.float()
+    model(x.float())
+    assert calls(model) == 2
+
+
+def test_plan_follows_weight_updates_and_new_shapes(dev):
+    model = util.build_model('yolov5s').eval().half().to(dev)
+    x = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(0)).half().to(dev)
+    z0, _ = model(x)
+    with torch.no_grad():
+        model.model[-1].m[0].bias.add_(1.0)
+    z1, _ = model(x)
+    assert not torch.equal(z0, z1), 'an in-place parameter update must rebuild the packed plan'
+    with engine.disabled():
+        zt, _ = model(x)
+    agree(z1, zt, 0.90)
+    z2, _ = model(torch.rand(3, 3, 96, 128).half().to(dev))
+    assert z2.shape == (3, 3 * (12 * 16 + 6 * 8 + 3 * 4), 85) and calls(model) == 3
+
+
+def test_test_time_augmentation_runs_on_the_engine(dev):
+    model = util.build_model('yolov5s').eval().half().to(dev)
+    x = torch.rand(1, 3, 128, 128).half().to(dev)
+    y, none = model(x, augment=True)
+    assert none is None and calls(model) == 3 and y.shape[0] == 1 and y.shape[2] == 85

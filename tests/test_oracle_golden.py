@@ -1,0 +1,102 @@
+"""The CPU oracle (oracle/y5ref.py, oracle/nms_ref.c) against the fixtures generated from the imported reference."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+import util
+from oracle import nms_c, y5ref
+
+OPS32 = y5ref._Ops('fp32')
+
+
+@pytest.mark.parametrize('name', util.BLOCKS)
+def test_block_matches_reference(name):
+    z = util.golden('block_' + name)
+    sd, x = util.sd_of(z), torch.from_numpy(z['x'])
+    if name.startswith('conv'):
+        y = y5ref.conv_block(OPS32, sd, 'model.0', x, 2 if 's2' in name else 1)
+    elif name == 'focus':
+        y = y5ref.conv_block(OPS32, sd, 'model.0.conv', y5ref.focus_gather(x))
+    elif name.startswith('bottleneck'):
+        y = y5ref.bottleneck(OPS32, sd, 'model.0', x, 'noadd' not in name)
+    elif name.startswith('csp'):
+        n = sum(1 for k in sd if '.m.' in k and k.endswith('cv1.conv.weight'))
+        y = y5ref.bottleneck_csp(OPS32, sd, 'model.0', x, n, 'noshortcut' not in name)
+    else:
+        y = y5ref.spp(OPS32, sd, 'model.0', x)
+    assert torch.equal(y, torch.from_numpy(z['y']))
+
+
+@pytest.mark.parametrize('mode', ['nearest', 'bilinear'])
+def test_upsample_concat_matches_reference(mode):
+    z = util.golden('block_upsample_%s_concat' % mode)
+    y = torch.cat([y5ref.upsample2x(OPS32, torch.from_numpy(z['a']), mode), torch.from_numpy(z['b'])], 1)
+    assert torch.equal(y, torch.from_numpy(z['y']))
+
+
+@pytest.mark.parametrize('tag', ['nc80_64x96', 'nc5_128x128', 'nc1_odd'])
+def test_half_decode_is_bit_exact(tag):
+    z = util.golden('decode_' + tag)
+    raw = [torch.from_numpy(z['raw%d' % i]) for i in range(3)]
+    zz, xs = y5ref.detect_decode(raw, torch.from_numpy(z['anchor_grid']), torch.from_numpy(z['stride']), True)
+    assert torch.equal(zz.view(torch.int16), torch.from_numpy(z['z']).view(torch.int16))
+    for i, t in enumerate(xs):
+        assert torch.equal(t, torch.from_numpy(z['x%d' % i]))
+
+
+NMS_CASES = ['multilabel', 'conf01', 'ties', 'agnostic', 'classes', 'over300', 'nc1', 'empty', 'half_input', 'single']
+
+
+@pytest.mark.parametrize('impl', [y5ref.non_max_suppression, nms_c.non_max_suppression], ids=['numpy', 'c'])
+@pytest.mark.parametrize('name', NMS_CASES)
+def test_nms_stage_list_matches_reference(name, impl):
+    z = util.golden('nms_' + name)
+    classes = list(z['classes']) if len(z['classes']) else None
+    out = impl(z['pred'], float(z['conf']), float(z['iou']), classes=classes, agnostic=bool(z['agnostic']))
+    for b, (det, flat, ncand) in enumerate(out):
+        assert len(det) == z['count'][b]
+        assert np.array_equal(det, z['det'][b, :len(det)])
+
+
+def test_c_and_numpy_box_nms_agree_on_random_boxes():
+    rng = np.random.default_rng(0)
+    for n, thr in ((1, 0.5), (50, 0.3), (2000, 0.6), (3000, 0.65)):
+        xy = rng.random((n, 2), np.float32) * 200
+        boxes = np.concatenate((xy, xy + rng.random((n, 2), np.float32) * 50 + 1), 1).astype(np.float32)
+        scores = (rng.integers(0, 50, n) / 50).astype(np.float32)  # many ties
+        assert np.array_equal(nms_c.nms(boxes, scores, thr), y5ref.nms_numpy(boxes, scores, thr))
+
+
+@pytest.mark.parametrize('cfg', ['yolov5s', 'yolov5s_ori'])
+def test_whole_graph_matches_reference(cfg):
+    z = util.golden('e2e_' + cfg)
+    model = util.build_model(cfg)
+    util.randomize_bn(model, 11)
+    sd = {k: v for k, v in model.state_dict().items()}
+    cfgd = yaml.safe_load(open(os.path.join(util.CFG_DIR, cfg + '.yaml')))
+    for tag in ('a', 'b'):
+        x = torch.from_numpy(z['x_' + tag])
+        zz, xs = y5ref.forward(cfgd, sd, x, precision='fp32', strides=model.stride)
+        assert torch.allclose(zz, torch.from_numpy(z['z_' + tag]), rtol=1e-5, atol=1e-5)
+        for i, t in enumerate(xs):
+            assert torch.allclose(t, torch.from_numpy(z['x%d_%s' % (i, tag)]), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('cfg', ['yolov5s', 'yolov5m', 'yolov5l', 'yolov5x', 'yolov5s_ori'])
+def test_graph_parse_matches_reference_channel_plan(cfg):
+    z = util.golden('graph_' + cfg)
+    shapes = dict(zip(z['keys'].tolist(), z['shapes'].tolist()))
+    cfgd = yaml.safe_load(open(os.path.join(util.CFG_DIR, cfg + '.yaml')))
+    for L in y5ref.parse_graph(cfgd):
+        pre = 'model.%d' % L['i']
+        if L['type'] == 'Conv':
+            assert shapes[pre + '.conv.weight'].split(';')[:2] == [str(L['c2']), str(L['c1'])]
+        elif L['type'] == 'BottleneckCSP':
+            assert shapes[pre + '.cv4.conv.weight'].split(';')[0] == str(L['c2'])
+            assert sum(1 for k in shapes if k.startswith(pre + '.m.') and k.endswith('cv1.conv.weight')) == L['repeat']
+        elif L['type'] == 'Detect':
+            assert [int(shapes['%s.m.%d.weight' % (pre, j)].split(';')[1]) for j in range(3)] == L['ch']

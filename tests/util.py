@@ -113,3 +113,33 @@ def block_from_fixture(name):
 
 BLOCKS = ['conv_k1s1', 'conv_k3s1', 'conv_k3s2', 'conv_k3s2_fused', 'conv_k3s1_odd', 'focus', 'bottleneck_add',
           'bottleneck_noadd', 'csp', 'csp_noshortcut', 'csp_fused', 'spp']
+
+
+def prune_like(model, fixture_name='graph_yolov5s_ori_pruned_a0', seed=0):
+    """Give `model` the irregular channel counts of a filter-pruned model: every conv / BatchNorm tensor is
+    re-created with the shape recorded in the fixture (which the reference's filter_pruning produced) and
+    seeded random values.  Shapes are what matters for the kernels; trained pruned weights do not exist offline."""
+    import torch.nn as nn
+    z = golden(fixture_name)
+    shapes = {k: tuple(int(v) for v in s.split(';')) if s else () for k, s in zip(z['keys'].tolist(), z['shapes'].tolist())}
+    g = torch.Generator().manual_seed(seed)
+    mods = dict(model.named_modules())
+    with torch.no_grad():
+        for name, m in mods.items():
+            if isinstance(m, nn.Conv2d):
+                shp = shapes[name + '.weight']
+                if tuple(m.weight.shape) != shp:
+                    fan_in = shp[1] * shp[2] * shp[3]
+                    m.weight = nn.Parameter((torch.rand(shp, generator=g) * 2 - 1) / fan_in ** 0.5)
+                    m.out_channels, m.in_channels = shp[0], shp[1]
+                    if m.bias is not None:
+                        m.bias = nn.Parameter(m.bias[:shp[0]].clone())
+            elif isinstance(m, nn.BatchNorm2d):
+                n = shapes[name + '.weight'][0]
+                if m.num_features != n:
+                    m.num_features = n
+                    m.weight = nn.Parameter(torch.ones(n))
+                    m.bias = nn.Parameter(torch.zeros(n))
+                    m.running_mean = torch.zeros(n)
+                    m.running_var = torch.ones(n)
+    return model

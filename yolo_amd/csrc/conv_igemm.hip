@@ -212,6 +212,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
                 cch -= a.Cin;
                 ++tap;
             }
+        } else {
+            cch = kpos;
         }
     };
 
