@@ -79,9 +79,13 @@ typedef struct y5_conv_desc {
     int32_t w_rows;             /* >= cout, multiple of 128                                         */
     int32_t act;                /* Y5_ACT_*                                                         */
     float slope;                /* LeakyReLU negative slope (0.1 in the reference)                  */
+    int32_t variant;            /* 0 = tile configuration chosen by rule; 1..y5_conv_num_variants() = explicit   */
 } y5_conv_desc;
 
 int y5_conv_f16(const y5_conv_desc* d, y5_stream_t stream);
+/* Number of compiled tile configurations of the convolution kernel (for autotuning the `variant` field: time
+ * each id on the real shape and keep the fastest; an id that does not apply to the shape returns Y5_EINVAL). */
+int y5_conv_num_variants(void);
 
 /* ------------------------------------------------------------------------------------------
  * Input packing: NCHW fp16 image batch -> NHWC fp16, optionally with the Focus space-to-depth

@@ -9,11 +9,14 @@ from yolo_amd import nms as hip_nms
 ap = argparse.ArgumentParser()
 ap.add_argument('--model', default='yolov5s'); ap.add_argument('--batch', type=int, default=32)
 ap.add_argument('--size', type=int, default=640); ap.add_argument('--passes', type=int, default=5)
-ap.add_argument('--nofuse', action='store_true')
+ap.add_argument('--nofuse', action='store_true'); ap.add_argument('--pruned', action='store_true'); ap.add_argument('--summary', action='store_true')
 a = ap.parse_args()
 torch.set_grad_enabled(False)
 dev = torch.device('cuda:0')
-m = util.build_model(a.model); util.calibrate(m, size=a.size)
+m = util.build_model(a.model)
+if a.pruned:
+    m = util.prune_like(m)
+util.calibrate(m, size=a.size)
 if not a.nofuse:
     m = util.quiet(m.fuse)
 m = m.eval().half().to(dev)
@@ -30,8 +33,11 @@ for _ in range(a.passes):
 tot = 0
 for r in acc:
     r['ms'] /= a.passes; tot += r['ms']
-    print('%3d %-8s %8.1f us %8.1f TF/s %8.0f GB/s  %s' % (r['op'], r['kind'], r['ms'] * 1e3, r['flops'] / r['ms'] / 1e9 if r['ms'] else 0, r['bytes'] / r['ms'] / 1e6 if r['ms'] else 0, r['label']))
-print('plan total %.3f ms' % tot)
+    if not a.summary: print('%3d %-8s %8.1f us %8.1f TF/s %8.0f GB/s  %s' % (r['op'], r['kind'], r['ms'] * 1e3, r['flops'] / r['ms'] / 1e9 if r['ms'] else 0, r['bytes'] / r['ms'] / 1e6 if r['ms'] else 0, r['label']))
+conv=[r for r in acc if r['kind']=='conv']
+cf=sum(r['flops'] for r in conv); cm=sum(r['ms'] for r in conv)
+print('%s batch %d: plan total %.3f ms, conv %.3f ms, %.1f GFLOP/img, conv aggregate %.1f TFLOP/s' % (a.model, a.batch, tot, cm, cf/a.batch/1e9, cf/cm/1e9))
+for r in sorted(conv, key=lambda r:-r['ms'])[:8]: print('   top: %7.1f us %7.1f TF/s %s' % (r['ms']*1e3, r['flops']/r['ms']/1e9, r['label']))
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()

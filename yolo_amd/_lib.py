@@ -20,7 +20,8 @@ class ConvDesc(C.Structure):
                 ('batch', C.c_int32), ('h', C.c_int32), ('w_in', C.c_int32), ('cin', C.c_int32), ('x_ld', C.c_int32),
                 ('ho', C.c_int32), ('wo', C.c_int32), ('cout', C.c_int32), ('y_ld', C.c_int32), ('res_ld', C.c_int32),
                 ('ksize', C.c_int32), ('stride', C.c_int32), ('pad', C.c_int32),
-                ('kpad', C.c_int32), ('w_rows', C.c_int32), ('act', C.c_int32), ('slope', C.c_float)]
+                ('kpad', C.c_int32), ('w_rows', C.c_int32), ('act', C.c_int32), ('slope', C.c_float),
+                ('variant', C.c_int32)]
 
 
 class DecodeDesc(C.Structure):
@@ -46,6 +47,7 @@ SIGNATURES = {
     'y5_last_error': (C.c_char_p, []),
     'y5_device_arch': (_i, [C.c_char_p, _i]),
     'y5_conv_f16': (_i, [C.POINTER(ConvDesc), _s]),
+    'y5_conv_num_variants': (_i, []),
     'y5_pack_image_f16': (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _s]),
     'y5_maxpool_f16': (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _s]),
     'y5_maxpool_cascade_f16': (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _s]),

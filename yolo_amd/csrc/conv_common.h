@@ -1,0 +1,96 @@
+// Pieces shared by the convolution kernels (included inside an anonymous namespace by each translation unit).
+#pragma once
+
+struct FastDiv {  // n / d for 0 <= n < 2^31 by multiply-high and shift
+    unsigned mul, shr, d;
+};
+
+inline FastDiv make_fastdiv(unsigned d) {
+    FastDiv f{0u, 0u, d};
+    if (d > 1) {
+        unsigned lg = 0;
+        while ((1ull << lg) < d) ++lg;
+        const unsigned p = 31 + lg;
+        f.mul = (unsigned)(((1ull << p) + d - 1) / d);
+        f.shr = p - 32;
+    }
+    return f;
+}
+
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) { return f.d == 1 ? n : (__umulhi(n, f.mul) >> f.shr); }
+
+struct ConvArgs {
+    const f16* x;
+    const f16* w;
+    const float* bias;
+    const float* scale;
+    const float* shift;
+    const f16* res;
+    f16* y;
+    long long M;  // batch*ho*wo
+    int H, W, Cin, x_ld;
+    int Ho, Wo, Cout, y_ld, res_ld;
+    int stride, pad, K;
+    int w_ld;     // weight row pitch in elements
+    int nk;       // K-steps to walk
+    int tiles_n, tiles_total;
+    float slope;  // 1.0 = no activation: leaky(v) = max(v, slope*v) for 0 < slope <= 1
+    FastDiv div_hw, div_wo, div_cin;
+    // halo-tile kernel only: output tiles per image and channel chunks
+    int tiles_x, tiles_y, nchunks;
+    FastDiv div_tpi, div_tx;
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    // Workgroups are dealt round-robin over the 8 XCDs; give each XCD one contiguous run of tiles
+    // so neighbouring tiles (which share input rows and weights) share an L2.  Bijective for any nwg.
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + (bid >> 3);
+}
+
+// 64 bytes of zeros: the source of every out-of-image / out-of-range 16-byte chunk, so that the
+// LDS-DMA below can always write a full tile without branching.
+static __device__ __attribute__((aligned(64))) unsigned int y5_zero_page[16];
+
+// One 16-byte-per-lane global -> LDS DMA (global_load_lds_dwordx4): the wave writes 1 KiB starting at the
+// wave-uniform LDS byte address lds_base, lane i at lds_base + 16*i, from each lane's own source address.
+// Issued from inline asm so that the compiler neither counts it nor drains it before later LDS reads;
+// completion is tracked by hand with s_waitcnt vmcnt(N).
+__device__ __forceinline__ void dma16(const void* src, unsigned lds_base) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(lds_base)
+        : "memory");
+}
+
+// Wait until at most n of this wave's vector-memory operations are outstanding, then meet the workgroup.
+__device__ __forceinline__ void wait_vm_and_barrier(int n) {
+#define Y5_WAIT_CASE(N) \
+    case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    switch (n) {
+        Y5_WAIT_CASE(1) Y5_WAIT_CASE(2) Y5_WAIT_CASE(3) Y5_WAIT_CASE(4) Y5_WAIT_CASE(5) Y5_WAIT_CASE(6)
+        Y5_WAIT_CASE(7) Y5_WAIT_CASE(8) Y5_WAIT_CASE(9) Y5_WAIT_CASE(10) Y5_WAIT_CASE(12) Y5_WAIT_CASE(16)
+        default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    }
+#undef Y5_WAIT_CASE
+}
+
+// Post-ops on four consecutive channels n..n+3 of one pixel (n % 4 == 0, n + 3 < Cout).
+__device__ __forceinline__ f16x4 post_op4(f32x4 v, int n, const ConvArgs& a) {
+    if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
+    f16x4 h = __builtin_convertvector(v, f16x4);
+    if (a.scale) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + n), sh = *reinterpret_cast<const f32x4*>(a.shift + n);
+        h = __builtin_convertvector(__builtin_convertvector(h, f32x4) * sc + sh, f16x4);
+    }
+    const f16x4 t = __builtin_convertvector(__builtin_convertvector(h, f32x4) * a.slope, f16x4);
+    return __builtin_elementwise_max(h, t);
+}
+

@@ -13,99 +13,13 @@
 // group.  The epilogue applies the per-channel post-ops on those groups of four with the reference's
 // fp16 rounding points, stages the tile in LDS and writes whole 16-byte channel vectors, adding the
 // residual there.
+#include <cstdlib>
+
 #include "y5_common.h"
 
 namespace {
 
-struct FastDiv {  // n / d for 0 <= n < 2^31 by multiply-high and shift
-    unsigned mul, shr, d;
-};
-
-FastDiv make_fastdiv(unsigned d) {
-    FastDiv f{0u, 0u, d};
-    if (d > 1) {
-        unsigned lg = 0;
-        while ((1ull << lg) < d) ++lg;
-        const unsigned p = 31 + lg;
-        f.mul = (unsigned)(((1ull << p) + d - 1) / d);
-        f.shr = p - 32;
-    }
-    return f;
-}
-
-__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) { return f.d == 1 ? n : (__umulhi(n, f.mul) >> f.shr); }
-
-struct ConvArgs {
-    const f16* x;
-    const f16* w;
-    const float* bias;
-    const float* scale;
-    const float* shift;
-    const f16* res;
-    f16* y;
-    long long M;  // batch*ho*wo
-    int H, W, Cin, x_ld;
-    int Ho, Wo, Cout, y_ld, res_ld;
-    int stride, pad, K;
-    int w_ld;     // weight row pitch in elements
-    int nk;       // K-steps to walk
-    int tiles_n, tiles_total;
-    float slope;  // 1.0 = no activation: leaky(v) = max(v, slope*v) for 0 < slope <= 1
-    FastDiv div_hw, div_wo, div_cin;
-};
-
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    // Workgroups are dealt round-robin over the 8 XCDs; give each XCD one contiguous run of tiles
-    // so neighbouring tiles (which share input rows and weights) share an L2.  Bijective for any nwg.
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return start + (bid >> 3);
-}
-
-// 64 bytes of zeros: the source of every out-of-image / out-of-range 16-byte chunk, so that the
-// LDS-DMA below can always write a full tile without branching.
-__device__ __attribute__((aligned(64))) unsigned int y5_zero_page[16];
-
-// One 16-byte-per-lane global -> LDS DMA (global_load_lds_dwordx4): the wave writes 1 KiB starting at the
-// wave-uniform LDS byte address lds_base, lane i at lds_base + 16*i, from each lane's own source address.
-// Issued from inline asm so that the compiler neither counts it nor drains it before later LDS reads;
-// completion is tracked by hand with s_waitcnt vmcnt(N).
-__device__ __forceinline__ void dma16(const void* src, unsigned lds_base) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(src), "s"(lds_base)
-        : "memory");
-}
-
-// Wait until at most n of this wave's vector-memory operations are outstanding, then meet the workgroup.
-__device__ __forceinline__ void wait_vm_and_barrier(int n) {
-#define Y5_WAIT_CASE(N) \
-    case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-    switch (n) {
-        Y5_WAIT_CASE(1) Y5_WAIT_CASE(2) Y5_WAIT_CASE(3) Y5_WAIT_CASE(4) Y5_WAIT_CASE(5) Y5_WAIT_CASE(6)
-        Y5_WAIT_CASE(8) Y5_WAIT_CASE(9) Y5_WAIT_CASE(10) Y5_WAIT_CASE(12) Y5_WAIT_CASE(16)
-        default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-    }
-#undef Y5_WAIT_CASE
-}
-
-// Post-ops on four consecutive channels n..n+3 of one pixel (n % 4 == 0, n + 3 < Cout).
-__device__ __forceinline__ f16x4 post_op4(f32x4 v, int n, const ConvArgs& a) {
-    if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
-    f16x4 h = __builtin_convertvector(v, f16x4);
-    if (a.scale) {
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + n), sh = *reinterpret_cast<const f32x4*>(a.shift + n);
-        h = __builtin_convertvector(__builtin_convertvector(h, f32x4) * sc + sh, f16x4);
-    }
-    const f16x4 t = __builtin_convertvector(__builtin_convertvector(h, f32x4) * a.slope, f16x4);
-    return __builtin_elementwise_max(h, t);
-}
+#include "conv_common.h"
 
 // BM x BN output tile, WM x WN waves, KS in {1,3}, S-deep LDS ring of BK-wide K-steps filled by DMA S-1 steps
 // ahead.  DIRECT: 1x1 stride-1 convolution, where output pixel m reads input pixel m (no coordinate decode).
@@ -317,6 +231,31 @@ int launch_tile(const ConvArgs& a0, int ksize, bool direct, hipStream_t s) {
     return Y5_OK;
 }
 
+// Every compiled tile configuration. Index + 1 is the public variant id (0 = choose by rule); ids past the end
+// of this table select the halo-tile kernel's channel widths (conv_halo.hip).
+struct Variant {
+    int bm, bn, bk, s;
+    int (*launch)(const ConvArgs&, int, bool, hipStream_t);
+};
+#define Y5_V(BM, BN, WM, WN, S, BK) {BM, BN, BK, S, &launch_tile<BM, BN, WM, WN, S, BK>}
+const Variant kVariants[] = {
+    Y5_V(128, 128, 2, 2, 2, 64), Y5_V(128, 128, 2, 2, 3, 32), Y5_V(128, 128, 2, 2, 4, 32),
+    Y5_V(128, 64, 2, 2, 2, 64),  Y5_V(128, 64, 2, 2, 3, 64),  Y5_V(128, 64, 2, 2, 3, 32),  Y5_V(128, 64, 2, 2, 4, 32),
+    Y5_V(64, 128, 2, 2, 2, 64),  Y5_V(64, 128, 2, 2, 3, 64),  Y5_V(64, 128, 2, 2, 3, 32),  Y5_V(64, 128, 2, 2, 4, 32),
+    Y5_V(64, 64, 2, 2, 2, 64),   Y5_V(64, 64, 2, 2, 3, 64),   Y5_V(64, 64, 2, 2, 4, 64),   Y5_V(64, 64, 2, 2, 3, 32),
+    Y5_V(64, 64, 2, 2, 4, 32),
+    Y5_V(128, 32, 4, 1, 2, 64),  Y5_V(128, 32, 4, 1, 3, 64),  Y5_V(128, 32, 4, 1, 3, 32),  Y5_V(128, 32, 4, 1, 4, 32),
+};
+#undef Y5_V
+constexpr int kNumIgemm = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
+constexpr int kNumHalo = 3;  // BN = 128, 64, 32
+
+int find_variant(int bm, int bn, int bk, int s) {
+    for (int i = 0; i < kNumIgemm; ++i)
+        if (kVariants[i].bm == bm && kVariants[i].bn == bn && kVariants[i].bk == bk && kVariants[i].s == s) return i;
+    return 0;
+}
+
 }  // namespace
 
 int y5_launch_conv(const y5_conv_desc& d, hipStream_t s) {
@@ -339,7 +278,14 @@ int y5_launch_conv(const y5_conv_desc& d, hipStream_t s) {
     Y5_REQUIRE(d.act == Y5_ACT_NONE || d.act == Y5_ACT_LEAKY, "conv: unknown activation %d", d.act);
     Y5_REQUIRE(d.act == Y5_ACT_NONE || (d.slope > 0.f && d.slope <= 1.f), "conv: LeakyReLU slope %g outside (0, 1]", (double)d.slope);
 
-    ConvArgs a;
+    Y5_REQUIRE(d.variant >= 0 && d.variant <= kNumIgemm + kNumHalo, "conv: variant %d out of range 0..%d", d.variant, kNumIgemm + kNumHalo);
+    if (d.variant > kNumIgemm || (d.variant == 0 && !getenv("Y5_NO_HALO"))) {
+        int rc = Y5_OK;
+        const int bn = d.variant == 0 ? 0 : (128 >> (d.variant - kNumIgemm - 1));
+        if (y5_try_conv_halo(d, s, bn, &rc)) return rc;
+        if (d.variant != 0) return y5_fail(Y5_EINVAL, "conv: the halo-tile variant %d does not apply to this shape", d.variant);
+    }
+    ConvArgs a{};
     a.x = static_cast<const f16*>(d.x);
     a.w = static_cast<const f16*>(d.w);
     a.bias = d.bias;
@@ -359,7 +305,9 @@ int y5_launch_conv(const y5_conv_desc& d, hipStream_t s) {
     a.div_cin = make_fastdiv((unsigned)d.cin);
     const bool direct = d.ksize == 1 && d.stride == 1;
 
-    // Tile choice. Channel width: the widest of {128, 64, 32} that wastes the fewest padded channels.
+    if (d.variant > 0) return kVariants[d.variant - 1].launch(a, d.ksize, direct, s);
+
+    // Rule-based choice. Channel width: the widest of {128, 64, 32} that wastes the fewest padded channels.
     // Pixel height: 128 rows unless that leaves the 256 CUs with fewer than ~4 workgroups each, in which
     // case 64-row tiles double the number of independent DMA streams.  K-step: 64 (whole 128-byte lines per
     // row) unless K is so short that rounding it up to 64 would mostly move padding.
@@ -368,15 +316,14 @@ int y5_launch_conv(const y5_conv_desc& d, hipStream_t s) {
     if (waste(64) < waste(bn)) bn = 64;
     if (waste(32) < waste(bn) && d.cout <= 32) bn = 32;
     const long long blocks128 = ((a.M + 127) / 128) * ((d.cout + bn - 1) / bn);
-    const bool small = blocks128 < 1024;
+    const bool small = blocks128 < 1024 && bn != 32;
     const int tail = a.K % 64;
     const bool k32 = a.K < 256 && tail != 0 && tail <= 32;
-    if (k32) {
-        if (bn == 128) return small ? launch_tile<64, 128, 2, 2, 4, 32>(a, d.ksize, direct, s) : launch_tile<128, 128, 2, 2, 3, 32>(a, d.ksize, direct, s);
-        if (bn == 64) return small ? launch_tile<64, 64, 2, 2, 4, 32>(a, d.ksize, direct, s) : launch_tile<128, 64, 2, 2, 4, 32>(a, d.ksize, direct, s);
-        return launch_tile<128, 32, 4, 1, 4, 32>(a, d.ksize, direct, s);
-    }
-    if (bn == 128) return small ? launch_tile<64, 128, 2, 2, 3, 64>(a, d.ksize, direct, s) : launch_tile<128, 128, 2, 2, 2, 64>(a, d.ksize, direct, s);
-    if (bn == 64) return small ? launch_tile<64, 64, 2, 2, 3, 64>(a, d.ksize, direct, s) : launch_tile<128, 64, 2, 2, 3, 64>(a, d.ksize, direct, s);
-    return launch_tile<128, 32, 4, 1, 3, 64>(a, d.ksize, direct, s);
+    const int bm = small ? 64 : 128;
+    int v;
+    if (k32) v = find_variant(bm, bn, 32, (bm == 128 && bn == 128) ? 3 : 4);
+    else v = find_variant(bm, bn, 64, (bm == 128 && bn == 128) ? 2 : 3);
+    return kVariants[v].launch(a, d.ksize, direct, s);
 }
+
+int y5_conv_variant_count() { return kNumIgemm + kNumHalo; }

@@ -23,6 +23,7 @@ from yolo_amd import _lib
 from yolo_amd.utils.torch_utils import bn_affine
 
 _DISABLED = [0]
+_TUNED = {}   # conv shape key -> fastest variant id, shared by all plans of the process
 
 
 class disabled:
@@ -238,8 +239,38 @@ class Plan:
             if not 0.0 < slope <= 1.0:
                 raise Unsupported('LeakyReLU slope %g' % slope)
             d.act, d.slope = _lib.ACT_LEAKY, slope
+        d.variant = self._tune(d, x)
         _lib.check(self.lib.y5_plan_add_conv(self.handle, C.byref(d)))
-        self.labels.append('%s conv%dx%d s%d %d->%d @%dx%d' % (label, k, k, s, x.c_log, out.c_log, ho, wo))
+        self.labels.append('%s conv%dx%d s%d %d->%d @%dx%d v%d' % (label, k, k, s, x.c_log, out.c_log, ho, wo, d.variant))
+
+    def _tune(self, d, x):
+        """Pick the fastest compiled tile configuration for this convolution by timing every applicable one on
+        the real shape (random activations, the layer's own weights).  Results are cached per shape for the
+        process; Y5_AUTOTUNE=0 keeps the rule-based choice (variant 0)."""
+        import os
+        if os.environ.get('Y5_AUTOTUNE', '1') == '0':
+            return 0
+        key = (d.batch, d.h, d.w_in, d.cin, d.x_ld, d.cout, d.y_ld, d.ksize, d.stride, bool(d.res), bool(d.bias), bool(d.scale))
+        if key in _TUNED:
+            return _TUNED[key]
+        x.buf.uniform_(-1.0, 1.0)
+        stream = _lib.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best, best_t = 0, float('inf')
+        for v in range(self.lib.y5_conv_num_variants() + 1):
+            d.variant = v
+            if self.lib.y5_conv_f16(C.byref(d), stream) != 0:
+                continue  # configuration does not apply to this shape
+            e0.record()
+            for _ in range(4):
+                self.lib.y5_conv_f16(C.byref(d), stream)
+            e1.record()
+            e1.synchronize()
+            t = e0.elapsed_time(e1)
+            if t < best_t:
+                best, best_t = v, t
+        _TUNED[key] = best
+        return best
 
     @staticmethod
     def _slope(act):
