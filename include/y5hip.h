@@ -87,6 +87,14 @@ int y5_conv_f16(const y5_conv_desc* d, y5_stream_t stream);
  * each id on the real shape and keep the fastest; an id that does not apply to the shape returns Y5_EINVAL). */
 int y5_conv_num_variants(void);
 
+/* Focus followed by its 3x3 stride-1 pad-1 convolution, straight from the NCHW image, without materialising the
+ * space-to-depth tensor.  Replaces: Focus.forward  models/common.py:85-86 (four strided slices + cat + self.conv).
+ * Same descriptor and post-ops as y5_conv_f16 with these meanings: x = image (batch, cin = 3, h, w_in) fp16 NCHW
+ * (x_ld unused), ho = h/2, wo = w_in/2 (h, w_in even); w = the convolution's weights packed as y5_conv_f16 wants
+ * them for the 16-channel (12 + 4 zero) space-to-depth input, i.e. k = (r*3 + q)*16 + (dy + 2*dx)*3 + c for image
+ * channel c at row parity dy, column parity dx; cout <= 96; res must be NULL; variant is ignored. */
+int y5_focus_conv_f16(const y5_conv_desc* d, y5_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Input packing: NCHW fp16 image batch -> NHWC fp16, optionally with the Focus space-to-depth
  * gather. Replaces: Focus.forward's four strided slices + cat  models/common.py:85-86
@@ -204,6 +212,7 @@ void y5_plan_destroy(y5_plan* p);
 /* Declare that device address `base` stands for external slot `slot` (0..15) while recording. */
 int y5_plan_bind_slot(y5_plan* p, int slot, const void* base, size_t bytes);
 int y5_plan_add_conv(y5_plan* p, const y5_conv_desc* d);
+int y5_plan_add_focus_conv(y5_plan* p, const y5_conv_desc* d);
 int y5_plan_add_pack_image(y5_plan* p, const void* x_nchw, void* y_nhwc, int batch, int c, int h, int w, int focus,
                            int y_ld);
 int y5_plan_add_maxpool(y5_plan* p, const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c,
@@ -228,6 +237,7 @@ int y5_plan_profile(y5_plan* p, void* const* ext, int n_ext, y5_stream_t stream,
 #define Y5_OP_COPY 5
 #define Y5_OP_DECODE 6
 #define Y5_OP_MAXPOOL_CASCADE 7
+#define Y5_OP_FOCUS_CONV 8
 int y5_plan_op_info(const y5_plan* p, int i, int* kind, double* flops, double* bytes);
 
 #ifdef __cplusplus

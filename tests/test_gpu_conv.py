@@ -48,8 +48,9 @@ def test_block_against_oracle(dev, name):
     assert exact > 0.98
 
 
-def run_conv(dev, x, w, bias=None, scale=None, shift=None, slope=None, res=None, stride=1):
-    """Call y5_conv_f16 directly. x (B,C,H,W) fp16, w (Co,C,k,k) fp16 -> (B,Co,Ho,Wo) fp16."""
+def run_conv(dev, x, w, bias=None, scale=None, shift=None, slope=None, res=None, stride=1, variant=0):
+    """Call y5_conv_f16 directly. x (B,C,H,W) fp16, w (Co,C,k,k) fp16 -> (B,Co,Ho,Wo) fp16.
+    With an explicit kernel variant, returns None when that variant does not take the shape."""
     lib = _lib.lib()
     B, Ci, H, W = x.shape
     Co, _, k, _ = w.shape
@@ -84,7 +85,11 @@ def run_conv(dev, x, w, bias=None, scale=None, shift=None, slope=None, res=None,
     d.ho, d.wo, d.cout, d.y_ld = Ho, Wo, cop, cop
     d.ksize, d.stride, d.pad, d.kpad, d.w_rows = k, stride, k // 2, kpad, rows
     d.act, d.slope = (_lib.ACT_LEAKY, slope) if slope is not None else (_lib.ACT_NONE, 0.0)
-    _lib.check(lib.y5_conv_f16(C.byref(d), _lib.current_stream()))
+    d.variant = variant
+    rc = lib.y5_conv_f16(C.byref(d), _lib.current_stream())
+    if variant and rc == _lib.EINVAL:
+        return None
+    _lib.check(rc)
     torch.cuda.synchronize()
     assert not bool(torch.isnan(y).any()), 'conv left output elements unwritten'
     assert bool((y[..., Co:] == 0).all()), 'padding channels must be zero'
@@ -126,6 +131,86 @@ def test_conv_kernel_against_torch_fp32(dev, shape):
     close(run_conv(dev, x, w, scale=scale, shift=shift, slope=0.1, res=res, stride=s), r2)
     # plain (no post-op)
     close(run_conv(dev, x, w, stride=s), acc.half())
+
+
+# Shapes for the explicit-variant sweep: ragged pixel counts (a partial last tile), K that is not a power of two,
+# channel counts below and above one tile.
+VARIANT_SHAPES = [
+    (3, 32, 32, 48, 41, 1, 1),
+    (2, 64, 128, 40, 40, 1, 1),
+    (1, 200, 72, 33, 17, 1, 1),
+    (5, 128, 255, 20, 12, 1, 1),
+    (9, 256, 256, 20, 20, 1, 1),
+    (2, 32, 64, 24, 41, 3, 1),
+    (1, 64, 136, 19, 23, 3, 1),
+    (2, 24, 48, 30, 30, 3, 2),
+]
+
+
+@pytest.mark.parametrize('shape', VARIANT_SHAPES, ids=lambda s: 'x'.join(map(str, s)))
+def test_every_kernel_variant_that_takes_the_shape(dev, shape):
+    """y5_conv_desc.variant selects a tile configuration / kernel family explicitly (the engine's autotuner does
+    so per layer): each one that accepts the shape must give the same result as the rule-chosen kernel's contract."""
+    B, Ci, Co, H, W, k, s = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, Ci, H, W, generator=g).half().to(dev)
+    w = (torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5).half().to(dev)
+    bias = torch.randn(Co, generator=g).to(dev)
+    scale, shift = (torch.rand(Co, generator=g) + 0.5).to(dev), torch.randn(Co, generator=g).to(dev)
+    acc = F.conv2d(x.float(), w.float(), None, s, k // 2)
+    ref_bias = F.leaky_relu((acc + bias.view(1, -1, 1, 1)).half().float(), 0.1).half()
+    ref_bn = (acc.half().float() * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).half()
+    taken = 0
+    for v in range(1, _lib.lib().y5_conv_num_variants() + 1):
+        got = run_conv(dev, x, w, bias=bias, slope=0.1, stride=s, variant=v)
+        if got is None:
+            continue
+        taken += 1
+        close(got, ref_bias)
+        close(run_conv(dev, x, w, scale=scale, shift=shift, stride=s, variant=v), ref_bn)
+        close(run_conv(dev, x, w, stride=s, variant=v), acc.half())
+    assert taken >= 10
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 96, 32), (3, 42, 74, 32), (1, 128, 66, 48), (2, 36, 130, 80), (1, 640, 640, 32)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_focus_conv_from_the_nchw_image(dev, shape):
+    """y5_focus_conv_f16 (Focus gather + 3x3 convolution in one kernel) against torch fp32 on the same fp16 operands:
+    ragged tiles, 1..3 channel groups, both post-op forms, output into a wider buffer."""
+    lib = _lib.lib()
+    B, H, W, Co = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    img = torch.randn(B, 3, H, W, generator=g).half().to(dev)
+    w = (torch.randn(Co, 12, 3, 3, generator=g) / 108 ** 0.5).half().to(dev)
+    bias = torch.randn(Co, generator=g).to(dev)
+    scale, shift = (torch.rand(Co, generator=g) + 0.5).to(dev), torch.randn(Co, generator=g).to(dev)
+    s2d = torch.cat([img[..., ::2, ::2], img[..., 1::2, ::2], img[..., ::2, 1::2], img[..., 1::2, 1::2]], 1)
+    acc = F.conv2d(s2d.float(), w.float(), None, 1, 1)
+    wp = torch.zeros(128, 192, dtype=torch.float16, device=dev)
+    wv = torch.zeros(Co, 3, 3, 16, dtype=torch.float16, device=dev)
+    wv[..., :12] = w.permute(0, 2, 3, 1)
+    wp[:Co, :144] = wv.reshape(Co, 144)
+    ld = Co + 8
+    for mode in ('bias', 'bn', 'plain'):
+        y = torch.full((B, H // 2, W // 2, ld), 7.0, dtype=torch.float16, device=dev)
+        d = _lib.ConvDesc()
+        d.x, d.w, d.y = img.data_ptr(), wp.data_ptr(), y.data_ptr()
+        d.batch, d.h, d.w_in, d.cin = B, H, W, 3
+        d.ho, d.wo, d.cout, d.y_ld = H // 2, W // 2, Co, ld
+        d.ksize, d.stride, d.pad, d.kpad, d.w_rows = 3, 1, 1, 192, 128
+        if mode == 'bias':
+            d.bias, d.act, d.slope = bias.data_ptr(), _lib.ACT_LEAKY, 0.1
+            ref = F.leaky_relu((acc + bias.view(1, -1, 1, 1)).half().float(), 0.1).half()
+        elif mode == 'bn':
+            d.scale, d.shift, d.act, d.slope = scale.data_ptr(), shift.data_ptr(), _lib.ACT_LEAKY, 0.1
+            ref = (acc.half().float() * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).half()
+            ref = F.leaky_relu(ref.float(), 0.1).half()
+        else:
+            ref = acc.half()
+        _lib.check(lib.y5_focus_conv_f16(C.byref(d), _lib.current_stream()))
+        torch.cuda.synchronize()
+        assert bool((y[..., Co:] == 7).all()), 'wrote outside its channel slice'
+        close(y[..., :Co].permute(0, 3, 1, 2), ref)
 
 
 def test_conv_into_channel_slice_leaves_neighbours_alone(dev):

@@ -40,6 +40,11 @@ extern "C" int y5_conv_f16(const y5_conv_desc* d, y5_stream_t stream) {
     Y5_REQUIRE(d, "conv: null descriptor");
     return y5_launch_conv(*d, static_cast<hipStream_t>(stream));
 }
+extern "C" int y5_focus_conv_f16(const y5_conv_desc* d, y5_stream_t stream) {
+    Y5_REQUIRE(d, "focus_conv: null descriptor");
+    return y5_launch_focus_conv(*d, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int y5_conv_num_variants(void) { return y5_conv_variant_count(); }
 extern "C" int y5_pack_image_f16(const void* x, void* y, int batch, int c, int h, int w, int focus, int y_ld,
                                  y5_stream_t stream) {
@@ -121,6 +126,7 @@ bool set_ptr(Op& op, int field, const void* v) {
     void* nv = const_cast<void*>(v);
     switch (op.kind) {
         case Y5_OP_CONV:
+        case Y5_OP_FOCUS_CONV:
             if (field == 0) op.conv.x = v;
             else if (field == 1) op.conv.y = nv;
             else if (field == 2) op.conv.res = v;
@@ -143,6 +149,7 @@ bool set_ptr(Op& op, int field, const void* v) {
 int run_op(const Op& op, hipStream_t s) {
     switch (op.kind) {
         case Y5_OP_CONV: return y5_launch_conv(op.conv, s);
+        case Y5_OP_FOCUS_CONV: return y5_launch_focus_conv(op.conv, s);
         case Y5_OP_PACK: return y5_launch_pack_image(op.px, op.py, op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], s);
         case Y5_OP_MAXPOOL: return y5_launch_maxpool(op.px, op.i[0], op.py, op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6], s);
         case Y5_OP_MAXPOOL_CASCADE:
@@ -211,6 +218,22 @@ extern "C" int y5_plan_add_conv(y5_plan* p, const y5_conv_desc* d) {
         op.flops = 2.0 * m * d->cout * d->ksize * d->ksize * d->cin;
         op.bytes = 2.0 * ((double)d->batch * d->h * d->w_in * d->cin + m * d->cout * (d->res ? 2 : 1) +
                           (double)d->cout * d->ksize * d->ksize * d->cin);
+        p->ops.push_back(op);
+        return Y5_OK;
+    });
+}
+
+extern "C" int y5_plan_add_focus_conv(y5_plan* p, const y5_conv_desc* d) {
+    Y5_REQUIRE(p && d, "plan_add_focus_conv: null argument");
+    return guarded([&]() {
+        Op op;
+        op.kind = Y5_OP_FOCUS_CONV;
+        op.conv = *d;
+        note_ptr(p, op, 0, d->x);
+        note_ptr(p, op, 1, d->y);
+        const double m = (double)d->batch * d->ho * d->wo;
+        op.flops = 2.0 * m * d->cout * 9 * 4 * d->cin;
+        op.bytes = 2.0 * ((double)d->batch * d->h * d->w_in * d->cin + m * d->cout + (double)d->cout * 9 * 4 * d->cin);
         p->ops.push_back(op);
         return Y5_OK;
     });

@@ -40,7 +40,10 @@ static inline bool y5_aligned16(const void* p) { return (reinterpret_cast<uintpt
 int y5_launch_conv(const y5_conv_desc& d, hipStream_t s);
 // 3x3 stride-1 halo-tile kernel (conv_halo.hip): returns 1 and sets *rc when it took the convolution.
 int y5_try_conv_halo(const y5_conv_desc& d, hipStream_t s, int force_bn, int* rc);
+int y5_try_conv_ws1x1(const y5_conv_desc& d, hipStream_t s, int which, int* rc);
 int y5_conv_variant_count();
+// Focus gather + 3x3 convolution from the NCHW image (conv_focus.hip); d.x is the image, d.cin its 3 channels.
+int y5_launch_focus_conv(const y5_conv_desc& d, hipStream_t s);
 int y5_launch_pack_image(const void* x, void* y, int batch, int c, int h, int w, int focus, int y_ld, hipStream_t s);
 int y5_launch_maxpool(const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c, int k, hipStream_t s);
 int y5_launch_maxpool_cascade(const void* x, int x_ld, void* y, int y_ld, int y_step, int levels, int batch, int h, int w, int c,

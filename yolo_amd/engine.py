@@ -15,6 +15,7 @@ makes pruned models work, and the plan is rebuilt whenever parameters change ide
 """
 import ctypes as C
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -204,9 +205,11 @@ class Plan:
         return packed, kpad, rows
 
     # ------------------------------------------------------------------ op emitters
-    def _emit_conv(self, label, x, weights, k, s, out, bias=None, scale=None, shift=None, slope=None, res=None):
+    def _emit_conv(self, label, x, weights, k, s, out, bias=None, scale=None, shift=None, slope=None, res=None, image=None):
         """Record one convolution. weights: row groups [(tensor, padded rows)] matching out.segs; out: Act slice to
-        write; bias/scale/shift: fp32 vectors of out.c_pad entries (or None); slope: LeakyReLU slope or None."""
+        write; bias/scale/shift: fp32 vectors of out.c_pad entries (or None); slope: LeakyReLU slope or None.
+        image: the NCHW input batch when this is Focus's convolution read straight from it (x then only describes
+        the space-to-depth tensor that is never built)."""
         for w, _ in weights:
             if w.dtype is not torch.float16 or w.device != self.device:
                 raise Unsupported('conv weights must be fp16 on the input device')
@@ -218,7 +221,7 @@ class Plan:
             raise Unsupported('conv output size mismatch')
         packed, kpad, rows = self._pack_weight(weights, x.segs)
         d = _lib.ConvDesc()
-        d.x, d.w, d.y = x.ptr, packed.data_ptr(), out.ptr
+        d.x, d.w, d.y = (x.ptr if image is None else image.data_ptr()), packed.data_ptr(), out.ptr
         cpad = out.c_pad
         if bias is not None:
             d.bias = self._f32(bias, cpad).data_ptr()
@@ -239,6 +242,11 @@ class Plan:
             if not 0.0 < slope <= 1.0:
                 raise Unsupported('LeakyReLU slope %g' % slope)
             d.act, d.slope = _lib.ACT_LEAKY, slope
+        if image is not None:
+            d.batch, d.h, d.w_in, d.cin, d.x_ld = image.shape[0], image.shape[2], image.shape[3], image.shape[1], 0
+            _lib.check(self.lib.y5_plan_add_focus_conv(self.handle, C.byref(d)))
+            self.labels.append('%s focus+conv3x3 %d->%d @%dx%d' % (label, x.c_log, out.c_log, ho, wo))
+            return
         d.variant = self._tune(d, x)
         _lib.check(self.lib.y5_plan_add_conv(self.handle, C.byref(d)))
         self.labels.append('%s conv%dx%d s%d %d->%d @%dx%d v%d' % (label, k, k, s, x.c_log, out.c_log, ho, wo, d.variant))
@@ -247,7 +255,6 @@ class Plan:
         """Pick the fastest compiled tile configuration for this convolution by timing every applicable one on
         the real shape (random activations, the layer's own weights).  Results are cached per shape for the
         process; Y5_AUTOTUNE=0 keeps the rule-based choice (variant 0)."""
-        import os
         if os.environ.get('Y5_AUTOTUNE', '1') == '0':
             return 0
         key = (d.batch, d.h, d.w_in, d.cin, d.x_ld, d.cout, d.y_ld, d.ksize, d.stride, bool(d.res), bool(d.bias), bool(d.scale))
@@ -280,23 +287,38 @@ class Plan:
             return float(act.negative_slope)
         raise Unsupported('activation %s' % type(act).__name__)
 
-    def _conv(self, label, x, conv, out, bias=None, affine=None, act=None, res=None):
+    def _conv(self, label, x, conv, out, bias=None, affine=None, act=None, res=None, image=None):
         """One nn.Conv2d with optional bias, folded BatchNorm (scale, shift) and activation module."""
         k, s = _conv_geometry(conv)
         if len(out.segs) != 1:
             raise Unsupported('conv output slice mismatch')
         self._emit_conv(label, x, [(conv.weight, out.segs[0][1])], k, s, out, bias=bias,
                         scale=None if affine is None else affine[0], shift=None if affine is None else affine[1],
-                        slope=self._slope(act), res=res)
+                        slope=self._slope(act), res=res, image=image)
 
-    def _conv_block(self, label, m, x, out, res=None):
+    def _conv_block(self, label, m, x, out, res=None, image=None):
         """A models.common.Conv (conv + BatchNorm + activation, or its fused form)."""
         if m.bn is None:
-            self._conv(label, x, m.conv, out, bias=m.conv.bias, act=m.act, res=res)
+            self._conv(label, x, m.conv, out, bias=m.conv.bias, act=m.act, res=res, image=image)
         else:
             if m.conv.bias is not None:
                 raise Unsupported('unfused Conv with conv bias')
-            self._conv(label, x, m.conv, out, affine=bn_affine(m.bn), act=m.act, res=res)
+            self._conv(label, x, m.conv, out, affine=bn_affine(m.bn), act=m.act, res=res, image=image)
+
+    def _focus(self, name, m, image, out):
+        """models.common.Focus on the plan's input image (NCHW): one fused kernel when its convolution is the usual
+        3x3 stride-1 over 3 image channels and at most 96 filters, else space-to-depth packing + convolution."""
+        B, cin, H, W = image.shape
+        k, s = _conv_geometry(m.conv.conv)
+        segs = [(4 * cin, pad8(4 * cin))]
+        if cin == 3 and (k, s) == (3, 1) and out.c_pad <= 96 and os.environ.get('Y5_FOCUS_FUSE', '1') != '0':
+            shape_only = Act(None, 0, segs[0][1], B, H // 2, W // 2, segs)
+            self._conv_block(name, m.conv, shape_only, out, image=image)
+            return
+        packed = self._new_act(B, H // 2, W // 2, segs)
+        _lib.check(self.lib.y5_plan_add_pack_image(self.handle, image.data_ptr(), packed.ptr, B, cin, H, W, 1, packed.ld))
+        self.labels.append('%s pack focus' % name)
+        self._conv_block(name, m.conv, packed, out)
 
     def _out_for(self, idx, batch, h, w, c_log):
         """Destination of top-level layer idx: its slice of a later concat buffer, or a fresh buffer."""
@@ -398,11 +420,8 @@ class Plan:
             if isinstance(m, common.Focus):
                 if i != 0 or f != -1:
                     raise Unsupported('Focus must be the first layer')
-                packed = self._new_act(B, H // 2, W // 2, [(4 * self.cin, pad8(4 * self.cin))])
-                _lib.check(self.lib.y5_plan_add_pack_image(self.handle, image.data_ptr(), packed.ptr, B, self.cin, H, W, 1, packed.ld))
-                self.labels.append('%s pack focus' % name)
                 out = self._out_for(i, B, h, w, c_log)
-                self._conv_block(name, m.conv, packed, out)
+                self._focus(name, m, image, out)
             elif isinstance(m, common.Conv):
                 if i == 0:
                     xin = self._new_act(B, H, W, [(self.cin, pad8(self.cin))])
@@ -448,20 +467,20 @@ class Plan:
         image = torch.zeros_like(x)
         self.keep.append(image)
         _lib.check(self.lib.y5_plan_bind_slot(self.handle, 0, image.data_ptr(), image.numel() * 2))
-        focus = isinstance(m, common.Focus)
-        xin = self._new_act(B, H // 2 if focus else H, W // 2 if focus else W,
-                            [(4 * self.cin, pad8(4 * self.cin))] if focus else [(self.cin, pad8(self.cin))])
-        _lib.check(self.lib.y5_plan_add_pack_image(self.handle, image.data_ptr(), xin.ptr, B, self.cin, H, W, int(focus), xin.ld))
+        if isinstance(m, common.Focus):
+            k, s = _conv_geometry(m.conv.conv)
+            c = m.conv.conv.out_channels
+            out = self._new_act(B, (H // 2 - 1) // s + 1, (W // 2 - 1) // s + 1, [(c, pad8(c))])
+            self._focus('focus', m, image, out)
+            self.block_out = out
+            return
+        xin = self._new_act(B, H, W, [(self.cin, pad8(self.cin))])
+        _lib.check(self.lib.y5_plan_add_pack_image(self.handle, image.data_ptr(), xin.ptr, B, self.cin, H, W, 0, xin.ld))
         self.labels.append('pack')
-        conv = m.conv.conv if focus else (m.conv if isinstance(m, common.Conv) else m.cv4.conv if isinstance(m, common.BottleneckCSP)
-                                          else m.cv2.conv)
-        s = 1
-        if focus or isinstance(m, common.Conv):
-            s = _conv_geometry(conv)[1]
+        conv = m.conv if isinstance(m, common.Conv) else m.cv4.conv if isinstance(m, common.BottleneckCSP) else m.cv2.conv
+        s = _conv_geometry(conv)[1] if isinstance(m, common.Conv) else 1
         out = self._new_act(B, (xin.h - 1) // s + 1, (xin.w - 1) // s + 1, [(conv.out_channels, pad8(conv.out_channels))])
-        if focus:
-            self._conv_block('focus', m.conv, xin, out)
-        elif isinstance(m, common.Conv):
+        if isinstance(m, common.Conv):
             self._conv_block('conv', m, xin, out)
         elif isinstance(m, common.Bottleneck):
             self._bottleneck('bottleneck', m, xin, out)
