@@ -169,6 +169,25 @@ def test_nms_large_candidate_sets_sort_through_global_memory(dev):
     assert np.array_equal(kept[0, :len(ref[0][1])].cpu().numpy(), ref[0][1])
 
 
+def test_nms_sort_paths_by_candidate_count(dev):
+    """One batch whose images have 0 .. 20000 candidates: the sort picks its path per image on the device (nothing,
+    one chunk, several chunks merged through global memory, the one-workgroup fallback above 16384 keys)."""
+    counts = [0, 1, 2, 63, 2047, 2048, 2049, 4097, 9000, 16384, 16385, 20000]
+    N = 20000
+    g = torch.Generator().manual_seed(11)
+    pred = synth_prediction(11, len(counts), N, 1, frac=1.0)
+    pred[..., 4] = torch.rand(len(counts), N, generator=g) * 0.5 + 0.5
+    pred[..., 5] = torch.randint(20, 200, (len(counts), N), generator=g).float() / 200   # many exact score ties
+    for b, c in enumerate(counts):
+        pred[b, torch.randperm(N, generator=g)[c:], 4] = 0.0
+    ref = nms_c.non_max_suppression(pred.numpy(), 0.01, 0.45)
+    det, cnt, kept, ncand = hip_nms.nms_padded(pred.to(dev), 0.01, 0.45, return_index=True, max_candidates=32768)
+    for b, (rdet, ridx, rn) in enumerate(ref):
+        assert rn == counts[b] == int(ncand[b])
+        assert int(cnt[b]) == len(ridx) and np.array_equal(kept[b, :len(ridx)].cpu().numpy(), ridx)
+        assert np.array_equal(det[b, :len(ridx)].cpu().numpy(), rdet)
+
+
 def test_box_nms_primitive_and_merge_path(dev):
     g = torch.Generator().manual_seed(0)
     xy = torch.rand(3000, 2, generator=g) * 300

@@ -1,11 +1,13 @@
-// Batched non-maximum suppression for gfx950, three kernels per call and no host round trip:
+// Batched non-maximum suppression for gfx950, three stages per call and no host round trip:
 //   1. candidates: confidence filter + multi-label expansion.  Rows are staged through LDS with 16-byte
 //      loads, survivors are compacted with a wave scan and one atomic add per workgroup.
 //      Every surviving (anchor row, class) pair becomes one 64-bit sort key
 //      [descending-score bits | anchor_row*nc + class]; the slot order in the key buffer is
 //      irrelevant because the key itself carries the reference's tie order (lower index first).
-//   2. sort: one 1024-thread workgroup per image runs a bitonic sort of its keys in LDS
-//      (blocks of 16384 keys; larger sets take extra passes through global memory).
+//   2. sort: bitonic network over each image's keys.  Images of up to 16384 (padded) keys are sorted by one
+//      workgroup per 2048-key chunk, with the cross-chunk passes done in registers through global memory, so a
+//      batch fills the chip; larger images fall back to one 1024-thread workgroup per image.  The host does not
+//      know the counts: every kernel reads its image's counter and exits at once when it has nothing to do.
 //   3. select: one workgroup per image walks the sorted candidates 64 at a time.  The kept boxes
 //      live in LDS; 16 waves test the chunk against disjoint parts of the kept list and publish
 //      64-bit suppression masks, then wave 0 resolves the chunk greedily with ballots.  Selection
@@ -144,8 +146,10 @@ __device__ __forceinline__ void cmpxchg(u64& a, u64& b, bool up) {
     if ((a > b) == up) { const u64 t = a; a = b; b = t; }
 }
 
+// One workgroup per image; `min_p2` > 0 makes it skip images whose padded size is below it (those were sorted by the
+// chunked kernels further down).
 __global__ __launch_bounds__(SORT_THREADS) void nms_sort_kernel(u64* __restrict__ keys_all, int cap_pow2, int cap,
-                                                                const int* __restrict__ counters) {
+                                                                const int* __restrict__ counters, int min_p2) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64* s = reinterpret_cast<u64*>(smem_raw);
     const int b = blockIdx.x;
@@ -155,6 +159,7 @@ __global__ __launch_bounds__(SORT_THREADS) void nms_sort_kernel(u64* __restrict_
     if (n <= 1) return;
     int P = 64;
     while (P < n) P <<= 1;
+    if (P < min_p2) return;
     const int tid = threadIdx.x;
 
     if (P <= SORT_LDS_KEYS) {
@@ -220,6 +225,89 @@ __global__ __launch_bounds__(SORT_THREADS) void nms_sort_kernel(u64* __restrict_
             __syncthreads();
         }
     }
+}
+
+// Chunked bitonic sort for images of up to CHUNK_MAX_P2 padded keys: one workgroup per 2048-key chunk instead of one
+// per image, so that a batch of 32 images fills the chip instead of 32 of its 256 CUs.
+//   sort_chunks      every chunk sorted in LDS, alternating direction (stages k <= 2048 of the network)
+//   merge_global(k)  passes j = k/2 .. 2048 of stage k: partners in different chunks, 2^levels keys per thread in registers
+//   merge_chunks(k)  passes j = 1024 .. 1 of stage k inside each chunk, in LDS
+// Images beyond CHUNK_MAX_P2 keys are left to nms_sort_kernel (min_p2 = 2 * CHUNK_MAX_P2).
+constexpr int CHUNK = 2048, CHUNK_LOG2 = 11, CHUNK_MAX_P2 = 16384;
+
+__device__ __forceinline__ int padded_size(const int* counters, int b, int cap) {
+    int n = counters[b];
+    if (n > cap) n = cap;
+    int P = 64;
+    while (P < n) P <<= 1;
+    return n <= 1 ? 0 : P;
+}
+
+__global__ __launch_bounds__(1024) void nms_sort_chunks_kernel(u64* __restrict__ keys_all, int cap_pow2, int cap,
+                                                               const int* __restrict__ counters) {
+    __shared__ u64 s[CHUNK];
+    const int b = blockIdx.y, gbase = blockIdx.x * CHUNK, tid = threadIdx.x;
+    const int P = padded_size(counters, b, cap);
+    if (P == 0 || P > CHUNK_MAX_P2 || gbase >= P) return;
+    int n = counters[b];
+    if (n > cap) n = cap;
+    u64* g = keys_all + (long long)b * cap_pow2 + gbase;
+    for (int i = tid; i < CHUNK; i += 1024) s[i] = gbase + i < n ? g[i] : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= CHUNK; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int i = ((tid & ~(j - 1)) << 1) | (tid & (j - 1));
+            cmpxchg(s[i], s[i | j], ((gbase + i) & k) == 0);
+            __syncthreads();
+        }
+    }
+    const int lim = P < CHUNK ? P : CHUNK;  // a set smaller than a chunk keeps its own padded size
+    for (int i = tid; i < lim; i += 1024) g[i] = s[i];
+}
+
+template <int LEVELS>
+__global__ __launch_bounds__(256) void nms_merge_global_kernel(u64* __restrict__ keys_all, int cap_pow2, int cap,
+                                                               const int* __restrict__ counters, int k) {
+    constexpr int G = 1 << LEVELS;
+    const int b = blockIdx.y;
+    const int P = padded_size(counters, b, cap);
+    if (P < k || P > CHUNK_MAX_P2) return;
+    const int t = blockIdx.x * 256 + threadIdx.x;  // one thread per group of G keys
+    if (t >= P / G) return;
+    const int lo = t & (CHUNK - 1), hi = t >> CHUNK_LOG2;
+    const int base = (hi << (CHUNK_LOG2 + LEVELS)) | lo;
+    u64* g = keys_all + (long long)b * cap_pow2;
+    u64 v[G];
+#pragma unroll
+    for (int m = 0; m < G; ++m) v[m] = g[base | (m << CHUNK_LOG2)];
+    const bool up = (base & k) == 0;
+#pragma unroll
+    for (int bit = LEVELS - 1; bit >= 0; --bit)
+#pragma unroll
+        for (int m = 0; m < G; ++m)
+            if (!(m & (1 << bit))) cmpxchg(v[m], v[m | (1 << bit)], up);
+#pragma unroll
+    for (int m = 0; m < G; ++m) g[base | (m << CHUNK_LOG2)] = v[m];
+}
+
+__global__ __launch_bounds__(1024) void nms_merge_chunks_kernel(u64* __restrict__ keys_all, int cap_pow2, int cap,
+                                                                const int* __restrict__ counters, int k) {
+    __shared__ u64 s[CHUNK];
+    const int b = blockIdx.y, gbase = blockIdx.x * CHUNK, tid = threadIdx.x;
+    const int P = padded_size(counters, b, cap);
+    if (P < k || P > CHUNK_MAX_P2 || gbase >= P) return;
+    u64* g = keys_all + (long long)b * cap_pow2 + gbase;
+    s[tid] = g[tid];
+    s[tid + 1024] = g[tid + 1024];
+    __syncthreads();
+    const bool up = (gbase & k) == 0;
+    for (int j = CHUNK >> 1; j > 0; j >>= 1) {
+        const int i = ((tid & ~(j - 1)) << 1) | (tid & (j - 1));
+        cmpxchg(s[i], s[i | j], up);
+        __syncthreads();
+    }
+    g[tid] = s[tid];
+    g[tid + 1024] = s[tid + 1024];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -371,6 +459,33 @@ int ensure_sort_lds() {
     return Y5_OK;
 }
 
+// Sorts every image's keys: the chunked kernels for images of up to CHUNK_MAX_P2 padded keys, the one-workgroup kernel
+// for larger ones.  Which path an image takes is decided on the device from its counter; kernels of the other path exit
+// at once for it.
+int launch_sort(u64* keys, int cap_pow2, int cap, const int* counters, int batch, hipStream_t s) {
+    if (int rc = ensure_sort_lds()) return rc;
+    const int p2 = cap_pow2 < CHUNK_MAX_P2 ? cap_pow2 : CHUNK_MAX_P2;
+    const int chunks = (p2 + CHUNK - 1) / CHUNK;
+    hipLaunchKernelGGL(nms_sort_chunks_kernel, dim3((unsigned)chunks, (unsigned)batch), dim3(1024), 0, s, keys, cap_pow2, cap, counters);
+    Y5_LAUNCH_CHECK("nms_sort_chunks_kernel");
+    for (int k = 2 * CHUNK; k <= p2; k <<= 1) {
+        const int levels = __builtin_ctz((unsigned)(k / CHUNK));
+        const dim3 ggrid((unsigned)((p2 >> levels) + 255) / 256, (unsigned)batch);
+        if (levels == 1) hipLaunchKernelGGL(nms_merge_global_kernel<1>, ggrid, dim3(256), 0, s, keys, cap_pow2, cap, counters, k);
+        else if (levels == 2) hipLaunchKernelGGL(nms_merge_global_kernel<2>, ggrid, dim3(256), 0, s, keys, cap_pow2, cap, counters, k);
+        else hipLaunchKernelGGL(nms_merge_global_kernel<3>, ggrid, dim3(256), 0, s, keys, cap_pow2, cap, counters, k);
+        Y5_LAUNCH_CHECK("nms_merge_global_kernel");
+        hipLaunchKernelGGL(nms_merge_chunks_kernel, dim3((unsigned)chunks, (unsigned)batch), dim3(1024), 0, s, keys, cap_pow2, cap, counters, k);
+        Y5_LAUNCH_CHECK("nms_merge_chunks_kernel");
+    }
+    if (cap_pow2 > CHUNK_MAX_P2) {
+        hipLaunchKernelGGL(nms_sort_kernel, dim3((unsigned)batch), dim3(SORT_THREADS), SORT_LDS_KEYS * sizeof(u64), s, keys, cap_pow2, cap,
+                           counters, 2 * CHUNK_MAX_P2);
+        Y5_LAUNCH_CHECK("nms_sort_kernel");
+    }
+    return Y5_OK;
+}
+
 }  // namespace
 
 extern "C" size_t y5_nms_workspace_bytes(int batch, int max_candidates) {
@@ -392,8 +507,6 @@ extern "C" int y5_nms_batched(const y5_nms_desc* d, y5_stream_t stream) {
     const size_t need = y5_nms_workspace_bytes(d->batch, d->max_candidates);
     if (d->workspace_bytes < need) return y5_fail(Y5_EWORKSPACE, "nms: workspace %zu < %zu bytes", d->workspace_bytes, need);
     Y5_REQUIRE(y5_aligned16(d->workspace), "nms: workspace must be 16-byte aligned");
-    if (int rc = ensure_sort_lds()) return rc;
-
     const size_t counters_bytes = ((size_t)d->batch * sizeof(int) + 255) / 256 * 256;
     int* counters = static_cast<int*>(d->workspace);
     u64* keys = reinterpret_cast<u64*>(static_cast<unsigned char*>(d->workspace) + counters_bytes);
@@ -411,9 +524,7 @@ extern "C" int y5_nms_batched(const y5_nms_desc* d, y5_stream_t stream) {
                            d->n_rows, d->no, d->conf_thres, d->class_keep, keys, cap_pow2, counters);
     Y5_LAUNCH_CHECK("nms_candidates_kernel");
 
-    hipLaunchKernelGGL(nms_sort_kernel, dim3((unsigned)d->batch), dim3(SORT_THREADS), SORT_LDS_KEYS * sizeof(u64), s, keys, cap_pow2,
-                       d->max_candidates, counters);
-    Y5_LAUNCH_CHECK("nms_sort_kernel");
+    if (int rc = launch_sort(keys, cap_pow2, d->max_candidates, counters, d->batch, s)) return rc;
 
     SelectArgs a;
     a.pred = d->pred; a.keys = keys; a.counters = counters;
@@ -445,14 +556,12 @@ extern "C" int y5_nms_boxes_f32(const float* boxes, const float* scores, int n, 
     Y5_REQUIRE(y5_aligned16(boxes) && y5_aligned16(workspace), "nms_boxes: boxes/workspace must be 16-byte aligned");
     const size_t need = y5_nms_workspace_bytes(1, n);
     if (workspace_bytes < need) return y5_fail(Y5_EWORKSPACE, "nms_boxes: workspace %zu < %zu bytes", workspace_bytes, need);
-    if (int rc = ensure_sort_lds()) return rc;
     int* counters = static_cast<int*>(workspace);
     u64* keys = reinterpret_cast<u64*>(static_cast<unsigned char*>(workspace) + 256);
     const int cap_pow2 = pow2_at_least(n);
     hipLaunchKernelGGL(nms_box_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scores, n, keys, counters);
     Y5_LAUNCH_CHECK("nms_box_keys_kernel");
-    hipLaunchKernelGGL(nms_sort_kernel, dim3(1), dim3(SORT_THREADS), SORT_LDS_KEYS * sizeof(u64), s, keys, cap_pow2, n, counters);
-    Y5_LAUNCH_CHECK("nms_sort_kernel");
+    if (int rc = launch_sort(keys, cap_pow2, n, counters, 1, s)) return rc;
     SelectArgs a;
     a.pred = boxes; a.keys = keys; a.counters = counters;
     a.det = nullptr; a.count = keep_count; a.kept_index = nullptr; a.n_candidates = nullptr; a.keep64 = reinterpret_cast<long long*>(keep);
