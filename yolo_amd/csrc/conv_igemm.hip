@@ -3,7 +3,7 @@
 //
 // GEMM view:  D[n][m] = sum_k Wt[n][k] * X[m][k]
 //   m = (b, oy, ox) output pixel, n = output channel, k = (r*ks + q)*cin + c.
-// One 256-thread workgroup (4 waves) owns a BM-pixel x BN-channel tile and walks K in steps of BK
+// One workgroup of 4 or 8 waves owns a BM-pixel x BN-channel tile and walks K in steps of BK
 // (32 or 64): the X tile is gathered (im2col on the fly, a zero page for padding) and the Wt tile copied
 // by 16-byte global->LDS DMA into an S-deep ring of LDS stages, S-1 steps ahead of the MFMAs, with
 // hand-counted s_waitcnt vmcnt and one barrier per step.  The LDS image is lane-linear per DMA
@@ -21,11 +21,28 @@ namespace {
 
 #include "conv_common.h"
 
+#ifdef Y5_STAMPS
+// Diagnostic build only (make dbg): per-wave cycle totals of the K loop's phases, read back by y5_debug_stamps().
+__device__ unsigned long long y5_stamp_buf[8 * 65536];
+#define Y5_STAMP(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#else
+#define Y5_STAMP(v)
+#endif
+
 // BM x BN output tile, WM x WN waves, KS in {1,3}, S-deep LDS ring of BK-wide K-steps filled by DMA S-1 steps
 // ahead.  DIRECT: 1x1 stride-1 convolution, where output pixel m reads input pixel m (no coordinate decode).
+template <int BM, int BN, int WM, int WN, int S, int BK>
+struct IgemmCfg {
+    static constexpr int NT = 64 * WM * WN;
+    static constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
+    static constexpr int EP = BN * 2 + 16;  // epilogue row pitch in bytes
+    static constexpr int SMEM = (S * STAGE_BYTES > BM * EP) ? S * STAGE_BYTES : BM * EP;
+};
+
 template <int BM, int BN, int WM, int WN, int KS, int S, int BK, bool DIRECT>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
-    static_assert(WM * WN == 4, "four waves per workgroup");
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs a) {
+    constexpr int NW = WM * WN, NT = 64 * NW;
+    static_assert(NW == 4 || NW == 8, "four or eight waves per workgroup");
     static_assert(BK == 32 || BK == 64, "K-step is 32 or 64");
     static_assert(!DIRECT || KS == 1, "direct addressing is for 1x1 convolutions");
     constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile: pixels x channels
@@ -33,15 +50,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     static_assert(RM >= 1 && RN >= 1, "wave tile must hold at least one MFMA tile");
     constexpr int ROW_BYTES = BK * 2;            // LDS bytes per tile row and step
     constexpr int CPRW = BK / 8;                 // 16-byte chunks per tile row (4 or 8)
-    constexpr int RPI = 256 / CPRW;              // tile rows one DMA instruction of the workgroup covers (64 or 32)
-    constexpr bool B_HALF = BN * CPRW < 256;     // weight tile smaller than one workgroup-wide DMA: waves 0,1 only
-    static_assert(BM % RPI == 0 && (BN % RPI == 0 || BN * CPRW == 128), "tile rows are staged RPI at a time");
+    constexpr int RPI = NT / CPRW;               // tile rows one DMA instruction of the workgroup covers
+    constexpr int B_WAVES = BN * CPRW < NT ? BN * CPRW / 64 : NW;  // a weight tile smaller than one workgroup-wide DMA is
+                                                                   // fetched by the first B_WAVES waves only
+    static_assert(BM % RPI == 0 && (BN % RPI == 0 || (BN * CPRW < NT && BN * CPRW % 64 == 0)), "tile rows are staged RPI at a time");
     constexpr int A_CH = BM / RPI;               // DMA instructions per wave and K-step for activations
     constexpr int B_CH = (BN + RPI - 1) / RPI;   // ... for weights
-    constexpr int STAGE_BYTES = (BM + BN) * ROW_BYTES;
-    constexpr int EP = BN * 2 + 16;              // epilogue row pitch in bytes
-    constexpr int SMEM = (S * STAGE_BYTES > BM * EP) ? S * STAGE_BYTES : BM * EP;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
+    constexpr int PIECE = NT * 16;               // LDS bytes one workgroup-wide DMA instruction fills
+    constexpr int STAGE_BYTES = IgemmCfg<BM, BN, WM, WN, S, BK>::STAGE_BYTES;
+    constexpr int EP = IgemmCfg<BM, BN, WM, WN, S, BK>::EP;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -77,7 +95,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
             xrow[i] = a.x + (size_t)b * a.H * a.W * a.x_ld;
         }
     }
-    const bool bload = !B_HALF || (wave < 2);  // wave-uniform
+    const bool bload = wave < B_WAVES;  // wave-uniform
     const f16* wptr[B_CH];
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) wptr[i] = a.w + (size_t)(n0 + (bload ? row0 : 0) + RPI * i) * a.w_ld + kc * 8;
@@ -91,34 +109,36 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     }
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
-    auto issue = [&](int stage) {
-        int r = 0, q = 0;
+    // One K-step's staging is A_CH + B_CH DMA instructions per wave, issued back to back.  (Spreading them between the
+    // MFMA groups of the step being multiplied was measured and gains nothing: the time goes into the DMA issue itself.)
+    int st_r = 0, st_q = 0;
+    bool st_kvalid = false;
+    auto step_begin = [&]() {
         if (KS > 1) {
-            r = (tap * 11) >> 5;  // tap / 3 for tap < 32
-            q = tap - 3 * r;
+            st_r = (tap * 11) >> 5;  // tap / 3 for tap < 32
+            st_q = tap - 3 * st_r;
         }
-        const bool kvalid = kpos < a.K;
-        const unsigned abase = lds0 + stage * STAGE_BYTES + wave * 1024;
-#pragma unroll
-        for (int i = 0; i < A_CH; ++i) {
+        st_kvalid = kpos < a.K;
+    };
+    auto issue_piece = [&](int p, int stage) {
+        if (p < A_CH) {
+            const int i = p;
             const void* src;
             if (DIRECT) {
-                src = (kvalid && mvalid[i]) ? (const void*)(xrow[i] + kpos) : (const void*)y5_zero_page;
+                src = (st_kvalid && mvalid[i]) ? (const void*)(xrow[i] + kpos) : (const void*)y5_zero_page;
             } else {
-                const int hi = hi0[i] + r, wi = wi0[i] + q;
-                const bool ok = kvalid && mvalid[i] && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+                const int hi = hi0[i] + st_r, wi = wi0[i] + st_q;
+                const bool ok = st_kvalid && mvalid[i] && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
                 src = ok ? (const void*)(xrow[i] + (size_t)(hi * a.W + wi) * a.x_ld + cch) : (const void*)y5_zero_page;
             }
-            dma16(src, abase + i * 4096);
+            dma16(src, lds0 + stage * STAGE_BYTES + wave * 1024 + i * PIECE);
+        } else if (bload) {
+            const int i = p - A_CH;
+            dma16(wptr[i], lds0 + stage * STAGE_BYTES + BM * ROW_BYTES + wave * 1024 + i * PIECE);
+            wptr[i] += BK;
         }
-        if (bload) {
-            const unsigned bbase = lds0 + stage * STAGE_BYTES + BM * ROW_BYTES + wave * 1024;
-#pragma unroll
-            for (int i = 0; i < B_CH; ++i) {
-                dma16(wptr[i], bbase + i * 4096);
-                wptr[i] += BK;
-            }
-        }
+    };
+    auto step_end = [&]() {
         kpos += BK;
         if (KS > 1) {
             cch += BK;
@@ -129,6 +149,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         } else {
             cch = kpos;
         }
+    };
+    auto issue = [&](int stage) {
+        step_begin();
+#pragma unroll
+        for (int p = 0; p < A_CH + B_CH; ++p) issue_piece(p, stage);
+        step_end();
     };
 
     f32x16 acc[RN][RM];
@@ -146,12 +172,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
     for (int s = 0; s < S - 1; ++s)
         if (s < nk) issue(s);
+#ifdef Y5_STAMPS
+    unsigned long long st_wait = 0, st_issue = 0, st_mma = 0;
+    const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+#endif
     for (int kt = 0; kt < nk; ++kt) {
         // K-steps kt+1 .. min(kt+S-2, nk-1) may stay in flight; step kt must have landed for every wave
         int ahead = nk - 1 - kt;
         if (ahead > S - 2) ahead = S - 2;
+        Y5_STAMP(s0);
         wait_vm_and_barrier(ahead * lps);
+        Y5_STAMP(s1);
         if (kt + S - 1 < nk) issue((kt + S - 1) % S);
+        Y5_STAMP(s2);
         const unsigned char* A = smem + (kt % S) * STAGE_BYTES;
         const unsigned char* B = A + BM * ROW_BYTES;
 #pragma unroll
@@ -170,8 +203,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
                 for (int i = 0; i < RM; ++i)
                     acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], xf[i], acc[j][i], 0, 0, 0);
         }
+#ifdef Y5_STAMPS
+        const unsigned long long s3 = __builtin_amdgcn_s_memtime();
+        st_wait += s1 - s0; st_issue += s2 - s1; st_mma += s3 - s2;
+#endif
     }
     wait_vm_and_barrier(0);  // every wave is done reading the ring before the epilogue reuses it
+#ifdef Y5_STAMPS
+    const unsigned long long st_loop_end = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- epilogue: post-ops in registers -> fp16 tile in LDS -> 16-byte stores (+ residual) ----
     // accumulator element e of MFMA tile (j,i): channel = 8*(e>>2) + 4*lh + (e&3) within the 32-channel
@@ -194,7 +234,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     }
     __syncthreads();
     constexpr int CPR = BN / 8;          // 16-byte chunks per tile row
-    constexpr int RPP = 256 / CPR;       // rows per pass
+    constexpr int RPP = NT / CPR;        // rows per pass
     const int cc = t % CPR, rr = t / CPR;
     const int n = n0 + cc * 8;
     if (n < a.Cout) {
@@ -209,7 +249,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
             }
         }
     }
+#ifdef Y5_STAMPS
+    if (lane == 0 && blockIdx.x * NW + wave < 65536) {
+        unsigned long long* o = y5_stamp_buf + (size_t)(blockIdx.x * NW + wave) * 8;
+        o[0] = st_wait; o[1] = st_issue; o[2] = st_mma; o[3] = st_loop_end - st_begin;
+        o[4] = __builtin_amdgcn_s_memtime() - st_loop_end; o[5] = st_begin; o[6] = nk;
+    }
+#endif
 }
+
+#ifdef Y5_STAMPS
+}  // namespace
+extern "C" int y5_debug_stamps(unsigned long long* dst, int n_waves) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(y5_stamp_buf), (size_t)n_waves * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
+namespace {
+#endif
 
 template <int BM, int BN, int WM, int WN, int S, int BK>
 int launch_tile(const ConvArgs& a0, int ksize, bool direct, hipStream_t s) {
@@ -220,13 +275,24 @@ int launch_tile(const ConvArgs& a0, int ksize, bool direct, hipStream_t s) {
     const long long total = tiles_m * a.tiles_n;
     if (total <= 0 || total > 0x7fffffffLL) return y5_fail(Y5_EINVAL, "conv: tile count %lld out of range", total);
     a.tiles_total = (int)total;
-    const dim3 grid((unsigned)total), block(256);
+    typedef IgemmCfg<BM, BN, WM, WN, S, BK> Cfg;
+    const dim3 grid((unsigned)total), block(Cfg::NT);
+    static bool attr_set = false;  // per process; LDS beyond 64 KiB has to be asked for once per kernel
+    if (!attr_set) {
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, 3, S, BK, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, 1, S, BK, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, 1, S, BK, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+        attr_set = true;
+    }
     if (ksize == 3)
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 3, S, BK, false>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 3, S, BK, false>), grid, block, Cfg::SMEM, s, a);
     else if (direct)
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1, S, BK, true>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1, S, BK, true>), grid, block, Cfg::SMEM, s, a);
     else
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1, S, BK, false>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1, S, BK, false>), grid, block, Cfg::SMEM, s, a);
     Y5_LAUNCH_CHECK("conv_igemm_kernel");
     return Y5_OK;
 }
@@ -245,6 +311,12 @@ const Variant kVariants[] = {
     Y5_V(64, 64, 2, 2, 2, 64),   Y5_V(64, 64, 2, 2, 3, 64),   Y5_V(64, 64, 2, 2, 4, 64),   Y5_V(64, 64, 2, 2, 3, 32),
     Y5_V(64, 64, 2, 2, 4, 32),
     Y5_V(128, 32, 4, 1, 2, 64),  Y5_V(128, 32, 4, 1, 3, 64),  Y5_V(128, 32, 4, 1, 3, 32),  Y5_V(128, 32, 4, 1, 4, 32),
+    // eight waves: the same LDS footprint hides twice the DMA latency
+    Y5_V(128, 128, 2, 4, 2, 64), Y5_V(128, 128, 2, 4, 3, 64), Y5_V(128, 128, 2, 4, 3, 32), Y5_V(128, 128, 2, 4, 4, 32),
+    Y5_V(256, 128, 4, 2, 2, 64), Y5_V(256, 128, 4, 2, 3, 32), Y5_V(256, 128, 4, 2, 2, 32),
+    Y5_V(128, 64, 4, 2, 2, 64),  Y5_V(128, 64, 4, 2, 3, 64),  Y5_V(64, 128, 2, 4, 2, 64),  Y5_V(64, 128, 2, 4, 3, 64),
+    // tall tiles for narrow layers: the weight tile is a smaller share of what every K-step stages
+    Y5_V(256, 64, 4, 2, 2, 64),  Y5_V(256, 64, 4, 2, 3, 32),  Y5_V(256, 32, 8, 1, 2, 64),  Y5_V(256, 32, 8, 1, 3, 32),
 };
 #undef Y5_V
 constexpr int kNumIgemm = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
