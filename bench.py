@@ -133,7 +133,7 @@ def main():
                     a['ms'] += r['ms']
         for a in acc:
             a['ms'] /= args.profile_passes
-        conv = [a for a in acc if a['kind'] == 'conv']
+        conv = [a for a in acc if a['kind'] in ('conv', 'focus_conv')]
         conv_ms = sum(a['ms'] for a in conv)
         conv_flops = sum(a['flops'] for a in conv)
         dec = [a for a in acc if a['kind'] == 'decode']

@@ -152,6 +152,11 @@ typedef struct y5_decode_desc {
 
 int y5_detect_decode_f16(const y5_decode_desc* d, y5_stream_t stream);
 
+/* y[i] = fp16(sigmoid(x[i])) for n fp16 values, the elementwise op of Detect.forward (x[i].sigmoid(), models/yolo.py:41)
+ * exactly as the decode kernel evaluates it.  libm = 0: the kernel's exp2/reciprocal form; libm = 1: 1/(1+expf(-x)) with
+ * IEEE division.  Both must agree on all 65536 inputs; the entry point exists so that this can be tested. */
+int y5_sigmoid_f16(const void* x, void* y, int64_t n, int libm, y5_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Batched non-maximum suppression.
  * Replaces: non_max_suppression  utils/utils.py:564-645 for merge=False (confidence filter,

@@ -117,6 +117,23 @@ def test_decode_full_size_level_against_oracle(dev):
     assert torch.equal(xo.cpu(), xr[0]) and torch.equal(zo.cpu().view(torch.int16), zr.view(torch.int16))
 
 
+def test_sigmoid_of_every_fp16_value(dev):
+    """The decode kernel's 4-instruction sigmoid against the libm/IEEE-division form and against torch's CPU half
+    sigmoid (the op the reference applies, models/yolo.py:41) on all 65536 bit patterns."""
+    lib = _lib.lib()
+    bits = torch.arange(65536, dtype=torch.int32).to(torch.int16)
+    x = bits.view(torch.float16).to(dev)
+    fast, slow = torch.empty_like(x), torch.empty_like(x)
+    _lib.check(lib.y5_sigmoid_f16(x.data_ptr(), fast.data_ptr(), 65536, 0, _lib.current_stream()))
+    _lib.check(lib.y5_sigmoid_f16(x.data_ptr(), slow.data_ptr(), 65536, 1, _lib.current_stream()))
+    torch.cuda.synchronize()
+    ref = torch.sigmoid(bits.view(torch.float16).float()).half()
+    finite = ~torch.isnan(ref)
+    assert torch.equal(fast.cpu().view(torch.int16)[finite], slow.cpu().view(torch.int16)[finite])
+    assert torch.equal(fast.cpu().view(torch.int16)[finite], ref.view(torch.int16)[finite])
+    assert bool(torch.isnan(fast.cpu()[~finite]).all())
+
+
 NMS_CASES = ['multilabel', 'conf01', 'ties', 'agnostic', 'classes', 'over300', 'nc1', 'empty', 'half_input', 'single']
 
 

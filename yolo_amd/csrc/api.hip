@@ -45,6 +45,9 @@ extern "C" int y5_focus_conv_f16(const y5_conv_desc* d, y5_stream_t stream) {
     return y5_launch_focus_conv(*d, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int y5_sigmoid_f16(const void* x, void* y, int64_t n, int libm, y5_stream_t stream) {
+    return y5_launch_sigmoid(x, y, n, libm, static_cast<hipStream_t>(stream));
+}
 extern "C" int y5_conv_num_variants(void) { return y5_conv_variant_count(); }
 extern "C" int y5_pack_image_f16(const void* x, void* y, int batch, int c, int h, int w, int focus, int y_ld,
                                  y5_stream_t stream) {

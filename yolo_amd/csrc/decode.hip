@@ -24,8 +24,18 @@ struct DecodeArgs {
     float anchor_wh[2 * Y5_MAX_ANCHORS];
 };
 
-// sigmoid in fp32, rounded once to fp16 like a half tensor's .sigmoid().
-__device__ __forceinline__ f16 sigmoid_h(f16 v) { return (f16)(1.f / (1.f + expf(-(float)v))); }
+// sigmoid in fp32, rounded once to fp16 like a half tensor's .sigmoid().  The hardware exp2 / reciprocal form below
+// gives the same fp16 as 1/(1 + expf(-x)) with IEEE division for every one of the 65536 fp16 inputs (checked
+// exhaustively by the tests through y5_sigmoid_f16), at 4 instructions instead of ~25.
+__device__ __forceinline__ f16 sigmoid_h(f16 v) {
+    return (f16)__builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-(float)v * 1.44269504088896341f));
+}
+__device__ __forceinline__ f16 sigmoid_h_libm(f16 v) { return (f16)(1.f / (1.f + expf(-(float)v))); }
+
+__global__ __launch_bounds__(256) void sigmoid_kernel(const f16* __restrict__ x, f16* __restrict__ y, long long n, int libm) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = libm ? sigmoid_h_libm(x[i]) : sigmoid_h(x[i]);
+}
 
 // One decoded element. o: output slot within the anchor record, (gx, gy): cell, (aw, ah): anchor.
 __device__ __forceinline__ f16 decode_one(f16 raw, int o, float gx, float gy, float aw, float ah, float stride) {
@@ -62,6 +72,21 @@ __global__ __launch_bounds__(kThreads) void detect_decode_kernel(const DecodeArg
     }
     __syncthreads();
 
+    // The four box slots of every (pixel, anchor) are decoded first, densely (one value per thread), into a small LDS
+    // array: inside the 8-wide output windows below they would be a divergent branch that nearly every wave takes.
+    f16* boxdec = tile + TP * a.lds_ld;  // [TP + 1][na][4]; the extra row is only ever read, by a window's unused tail
+    if (VEC) {
+        for (int i = threadIdx.x; i < np * a.na * 4; i += kThreads) {
+            const int o = i & 3, pa = i >> 2;
+            const int p = pa / a.na, an = pa - p * a.na;
+            const int pix = pix0 + p;
+            const int gy = pix / a.nx, gx = pix - gy * a.nx;
+            boxdec[i] = decode_one(tile[p * a.lds_ld + an * a.no + o], o, (float)gx, (float)gy, a.anchor_wh[2 * an],
+                                   a.anchor_wh[2 * an + 1], a.stride);
+        }
+        __syncthreads();
+    }
+
     const int run = np * a.no;  // contiguous outputs per anchor
     for (int an = 0; an < a.na; ++an) {
         const float aw = a.anchor_wh[2 * an], ah = a.anchor_wh[2 * an + 1];
@@ -74,15 +99,10 @@ __global__ __launch_bounds__(kThreads) void detect_decode_kernel(const DecodeArg
                 f16x8 raw, dec;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    f16 r = (f16)0.f, d = (f16)0.f;
-                    if (e0 + e < run) {
-                        r = col[p * a.lds_ld + o];
-                        const int pix = pix0 + p;
-                        const int gy = pix / a.nx, gx = pix - gy * a.nx;
-                        d = decode_one(r, o, (float)gx, (float)gy, aw, ah, a.stride);
-                    }
+                    const f16 r = e0 + e < run ? col[p * a.lds_ld + o] : (f16)0.f;
+                    const f16 bx = boxdec[(p * a.na + an) * 4 + (o & 3)];
                     raw[e] = r;
-                    dec[e] = d;
+                    dec[e] = o < 4 ? bx : sigmoid_h(r);
                     if (++o == a.no) { o = 0; ++p; }
                 }
                 if (e0 + 8 <= run) {
@@ -110,6 +130,15 @@ __global__ __launch_bounds__(kThreads) void detect_decode_kernel(const DecodeArg
 
 }  // namespace
 
+int y5_launch_sigmoid(const void* x, void* y, long long n, int libm, hipStream_t s) {
+    Y5_REQUIRE(n >= 0 && (n == 0 || (x && y)), "sigmoid: null pointer");
+    if (n == 0) return Y5_OK;
+    hipLaunchKernelGGL(sigmoid_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, static_cast<const f16*>(x),
+                       static_cast<f16*>(y), n, libm);
+    Y5_LAUNCH_CHECK("sigmoid_kernel");
+    return Y5_OK;
+}
+
 int y5_launch_decode(const y5_decode_desc& d, hipStream_t s) {
     Y5_REQUIRE(d.head && d.z_out, "decode: null pointer");
     Y5_REQUIRE(d.batch > 0 && d.ny > 0 && d.nx > 0, "decode: empty tensor");
@@ -120,7 +149,7 @@ int y5_launch_decode(const y5_decode_desc& d, hipStream_t s) {
     Y5_REQUIRE(d.head_ld % 8 == 0 && d.head_ld >= lds_ld, "decode: head_ld %d must be a multiple of 8 >= %d", d.head_ld, lds_ld);
     Y5_REQUIRE(y5_aligned16(d.head), "decode: head must be 16-byte aligned");
     Y5_REQUIRE(d.z_row0 >= 0 && (long long)d.z_row0 + (long long)d.na * d.ny * d.nx <= d.z_rows_total, "decode: rows %d..+%d exceed z_rows_total %d", d.z_row0, d.na * d.ny * d.nx, d.z_rows_total);
-    const size_t lds_bytes = (size_t)TP * lds_ld * sizeof(f16);
+    const size_t lds_bytes = ((size_t)TP * lds_ld + (size_t)(TP + 1) * d.na * 4) * sizeof(f16);  // staged pixels + decoded box slots
     Y5_REQUIRE(lds_bytes <= 64 * 1024, "decode: na*no = %d too large for the staging tile", chans);
 
     DecodeArgs a;
