@@ -48,8 +48,9 @@ __device__ __forceinline__ float ldf(const float* p) { return *p; }
 // One workgroup stages CAND_ROWS consecutive prediction rows in LDS with 16-byte loads (the rows are contiguous
 // in memory), then every thread scores a strided share of the (row, class) pairs from LDS, remembers the
 // survivors in a bit mask, the workgroup reserves key slots with ONE atomic add, and the survivors are written.
-constexpr int CAND_ROWS = 64;
-constexpr int CAND_THREADS = 256;
+constexpr int CAND_ROWS = 256;
+constexpr int CAND_THREADS = 1024;
+static_assert(CAND_THREADS == 4 * CAND_ROWS, "four threads score one staged row");
 
 template <typename T>
 __global__ __launch_bounds__(CAND_THREADS) void nms_candidates_kernel(const T* __restrict__ pred, int n_rows, int no, float conf_thres,
@@ -80,17 +81,20 @@ __global__ __launch_bounds__(CAND_THREADS) void nms_candidates_kernel(const T* _
     __syncthreads();
 
     u64* out = keys + (long long)b * cap;
-    const int pairs = nr * nc;
-    for (int chunk = 0; chunk < pairs; chunk += CAND_THREADS * 32) {
+    // Four threads per row: thread (row, part) scores classes part, part + 4, ... in chunks of 128 classes, so that a
+    // pair's row and class need no division and the row's objectness is read once.
+    const int row = tid >> 2, part = tid & 3;
+    const bool rvalid = row < nr;
+    const float obj = rvalid ? ldf(tile + row * no + 4) : 0.f;
+    const bool live = rvalid && obj > conf_thres;
+    for (int cbase = 0; cbase < nc; cbase += 128) {
         // ---- pass 1: which of this thread's pairs survive
         unsigned mask = 0;
+        if (live) {
 #pragma unroll 4
-        for (int i = 0; i < 32; ++i) {
-            const int e = chunk + tid + i * CAND_THREADS;
-            if (e < pairs) {
-                const int row = e / nc, c = e - row * nc;
-                const float obj = ldf(tile + row * no + 4);
-                if (obj > conf_thres) {
+            for (int i = 0; i < 32; ++i) {
+                const int c = cbase + part + 4 * i;
+                if (c < nc) {
                     const float conf = ldf(tile + row * no + 5 + c) * obj;  // conf = cls * obj in fp32
                     if (conf > conf_thres && (!class_keep || class_keep[c])) mask |= 1u << i;
                 }
@@ -116,14 +120,13 @@ __global__ __launch_bounds__(CAND_THREADS) void nms_candidates_kernel(const T* _
             block_base = sum ? atomicAdd(&counters[b], sum) : 0;
         }
         __syncthreads();
+        // ---- pass 2: write the survivors' keys (slots past the capacity are dropped; the counter keeps counting)
         int pos = block_base + wave_total[wave] + incl - cnt;
-        // ---- pass 2: write the keys
         while (mask) {
             const int i = __builtin_ctz(mask);
             mask &= mask - 1;
-            const int e = chunk + tid + i * CAND_THREADS;
-            const int row = e / nc, c = e - row * nc;
-            const float conf = ldf(tile + row * no + 5 + c) * ldf(tile + row * no + 4);
+            const int c = cbase + part + 4 * i;
+            const float conf = ldf(tile + row * no + 5 + c) * obj;
             if (pos < cap) out[pos] = ((u64)score_desc_bits(conf) << 32) | (unsigned)((r0 + row) * nc + c);
             ++pos;
         }
@@ -338,11 +341,53 @@ struct SelectArgs {
     int n_rows, no, cap, cap_pow2, max_det, agnostic;
 };
 
+// One candidate as every lane of every wave holds it: IoU box (class-offset in pred mode), reported box, score, class.
+struct Cand {
+    Box cb, ob;
+    float score, cls, carea;
+    unsigned flat;
+    bool valid;
+};
+
+template <typename T, bool BOXES>
+__device__ __forceinline__ Cand load_candidate(const SelectArgs& a, const u64* keys, int b, int ci, int n, int nc) {
+    Cand c;
+    c.cb = {0.f, 0.f, 0.f, 0.f};
+    c.ob = c.cb;
+    c.score = c.cls = 0.f;
+    c.flat = 0;
+    c.valid = ci < n;
+    if (c.valid) {
+        const u64 key = keys[ci];
+        c.flat = (unsigned)key;
+        c.score = score_from_bits((unsigned)(key >> 32));
+        if (BOXES) {
+            const float4 v = reinterpret_cast<const float4*>(a.pred)[c.flat];
+            c.cb = {v.x, v.y, v.z, v.w};
+            c.ob = c.cb;
+        } else {
+            const unsigned row = c.flat / (unsigned)nc;
+            const unsigned k = c.flat - row * (unsigned)nc;
+            const T* p = static_cast<const T*>(a.pred) + ((long long)b * a.n_rows + row) * a.no;
+            const float cx = ldf(p), cy = ldf(p + 1), bw = ldf(p + 2), bh = ldf(p + 3);
+            const float hw = bw / 2.f, hh = bh / 2.f;
+            c.ob = {__fsub_rn(cx, hw), __fsub_rn(cy, hh), __fadd_rn(cx, hw), __fadd_rn(cy, hh)};
+            c.cls = (float)k;
+            const float off = a.agnostic ? 0.f : __fmul_rn(c.cls, CLASS_OFFSET);
+            c.cb = {__fadd_rn(c.ob.x1, off), __fadd_rn(c.ob.y1, off), __fadd_rn(c.ob.x2, off), __fadd_rn(c.ob.y2, off)};
+        }
+    }
+    c.carea = __fmul_rn(__fsub_rn(c.cb.x2, c.cb.x1), __fsub_rn(c.cb.y2, c.cb.y1));
+    return c;
+}
+
 template <typename T, bool BOXES>
 __global__ __launch_bounds__(SEL_THREADS) void nms_select_kernel(const SelectArgs a) {
+    static_assert(SEL_WAVES * 4 == 64, "each wave fills four rows of the 64 x 64 chunk matrix");
     __shared__ Box kbox[MAX_DET_CAP];
     __shared__ float karea[MAX_DET_CAP];
     __shared__ u64 sup[SEL_WAVES];
+    __shared__ u64 mrow[64];  // mrow[i]: candidates of the chunk that candidate i suppresses if it is kept
     __shared__ int kcount;
 
     const int b = blockIdx.x;
@@ -358,74 +403,64 @@ __global__ __launch_bounds__(SEL_THREADS) void nms_select_kernel(const SelectArg
     }
     __syncthreads();
 
+    // every wave materialises the same 64 candidates; the next chunk is fetched while this one is resolved
+    Cand nxt = load_candidate<T, BOXES>(a, keys, b, lane, n, nc);
     for (int c0 = 0; c0 < n; c0 += 64) {
         const int K = kcount;  // stable between the barriers below
         if (K >= a.max_det) break;
-        // every wave materialises the same 64 candidates
-        const int ci = c0 + lane;
-        const bool valid = ci < n;
-        Box cb = {0.f, 0.f, 0.f, 0.f};   // box used for IoU (class-offset in pred mode)
-        Box ob = cb;                      // box reported
-        float score = 0.f, cls = 0.f;
-        unsigned flat = 0;
-        if (valid) {
-            const u64 key = keys[ci];
-            flat = (unsigned)key;
-            score = score_from_bits((unsigned)(key >> 32));
-            if (BOXES) {
-                const float4 v = reinterpret_cast<const float4*>(a.pred)[flat];
-                cb = {v.x, v.y, v.z, v.w};
-                ob = cb;
-            } else {
-                const unsigned row = flat / (unsigned)nc;
-                const unsigned c = flat - row * (unsigned)nc;
-                const T* p = static_cast<const T*>(a.pred) + ((long long)b * a.n_rows + row) * a.no;
-                const float cx = ldf(p), cy = ldf(p + 1), bw = ldf(p + 2), bh = ldf(p + 3);
-                const float hw = bw / 2.f, hh = bh / 2.f;
-                ob = {__fsub_rn(cx, hw), __fsub_rn(cy, hh), __fadd_rn(cx, hw), __fadd_rn(cy, hh)};
-                cls = (float)c;
-                const float off = a.agnostic ? 0.f : __fmul_rn(cls, CLASS_OFFSET);
-                cb = {__fadd_rn(ob.x1, off), __fadd_rn(ob.y1, off), __fadd_rn(ob.x2, off), __fadd_rn(ob.y2, off)};
-            }
-        }
-        const float carea = __fmul_rn(__fsub_rn(cb.x2, cb.x1), __fsub_rn(cb.y2, cb.y1));
+        const Cand c = nxt;
+        if (c0 + 64 < n) nxt = load_candidate<T, BOXES>(a, keys, b, c0 + 64 + lane, n, nc);
 
-        // kept-list test, kept entries strided over the waves
+        // (1) kept-list test, kept entries strided over the waves
         bool dead = false;
         for (int k = wave; k < K; k += SEL_WAVES) {
             const Box kb = kbox[k];
-            if (!dead && suppresses(kb, karea[k], cb, carea, a.iou_thres)) dead = true;
+            if (!dead && suppresses(kb, karea[k], c.cb, c.carea, a.iou_thres)) dead = true;
         }
         const u64 m = __ballot(dead);
         if (lane == 0) sup[wave] = m;
+        // (2) the chunk's own suppression matrix, four rows per wave
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = wave * 4 + r;
+            Box ib;
+            ib.x1 = __shfl(c.cb.x1, i); ib.y1 = __shfl(c.cb.y1, i); ib.x2 = __shfl(c.cb.x2, i); ib.y2 = __shfl(c.cb.y2, i);
+            const float iarea = __shfl(c.carea, i);
+            const bool sij = lane > i && c.valid && suppresses(ib, iarea, c.cb, c.carea, a.iou_thres);
+            const u64 row = __ballot(sij);
+            if (lane == 0) mrow[i] = row;
+        }
         __syncthreads();
 
+        // (3) wave 0 resolves the chunk greedily on the bit masks and writes the kept candidates
         if (wave == 0) {
             u64 all = 0;
 #pragma unroll
             for (int w = 0; w < SEL_WAVES; ++w) all |= sup[w];
-            u64 alive = __ballot(valid) & ~all;
+            const u64 my = mrow[lane];
+            const unsigned my_lo = (unsigned)my, my_hi = (unsigned)(my >> 32);
+            u64 alive = __ballot(c.valid) & ~all;
+            u64 keep = 0;
             int kk = K;
             while (alive && kk < a.max_det) {
                 const int i = __builtin_ctzll(alive);
-                alive &= alive - 1;
-                Box ib;
-                ib.x1 = __shfl(cb.x1, i); ib.y1 = __shfl(cb.y1, i); ib.x2 = __shfl(cb.x2, i); ib.y2 = __shfl(cb.y2, i);
-                const float iarea = __shfl(carea, i);
-                if (lane == i) {
-                    kbox[kk] = cb;
-                    karea[kk] = carea;
-                    if (BOXES) {
-                        a.keep64[kk] = (long long)flat;
-                    } else {
-                        float* d = a.det + ((long long)b * a.max_det + kk) * 6;
-                        d[0] = ob.x1; d[1] = ob.y1; d[2] = ob.x2; d[3] = ob.y2; d[4] = score; d[5] = cls;
-                        if (a.kept_index) a.kept_index[(long long)b * a.max_det + kk] = (int)flat;
-                    }
-                }
+                keep |= 1ull << i;
+                const u64 mi = ((u64)(unsigned)__builtin_amdgcn_readlane((int)my_hi, i) << 32) |
+                               (unsigned)__builtin_amdgcn_readlane((int)my_lo, i);
+                alive &= ~(mi | (1ull << i));
                 ++kk;
-                const bool s = lane > i && suppresses(ib, iarea, cb, carea, a.iou_thres);
-                alive &= ~__ballot(s);
+            }
+            if ((keep >> lane) & 1) {
+                const int pos = K + __builtin_popcountll(keep & ((1ull << lane) - 1));
+                kbox[pos] = c.cb;
+                karea[pos] = c.carea;
+                if (BOXES) {
+                    a.keep64[pos] = (long long)c.flat;
+                } else {
+                    float* d = a.det + ((long long)b * a.max_det + pos) * 6;
+                    d[0] = c.ob.x1; d[1] = c.ob.y1; d[2] = c.ob.x2; d[3] = c.ob.y2; d[4] = c.score; d[5] = c.cls;
+                    if (a.kept_index) a.kept_index[(long long)b * a.max_det + pos] = (int)c.flat;
+                }
             }
             if (lane == 0) kcount = kk;
         }
@@ -515,7 +550,13 @@ extern "C" int y5_nms_batched(const y5_nms_desc* d, y5_stream_t stream) {
     Y5_HIP(hipMemsetAsync(counters, 0, counters_bytes, s));
     const dim3 cgrid((unsigned)((d->n_rows + CAND_ROWS - 1) / CAND_ROWS), (unsigned)d->batch);
     const size_t tile_bytes = ((size_t)CAND_ROWS * d->no * (d->pred_dtype == 0 ? 2 : 4) + 15) / 16 * 16;
-    Y5_REQUIRE(tile_bytes <= 60 * 1024, "nms: %d values per row do not fit the staging tile", d->no);
+    Y5_REQUIRE(tile_bytes <= 150 * 1024, "nms: %d values per row do not fit the staging tile", d->no);
+    static bool cand_attr = false;  // per process: the staging tile may exceed the default 64 KiB of dynamic LDS
+    if (!cand_attr) {
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_candidates_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_candidates_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        cand_attr = true;
+    }
     if (d->pred_dtype == 0)
         hipLaunchKernelGGL(nms_candidates_kernel<f16>, cgrid, dim3(CAND_THREADS), tile_bytes, s, static_cast<const f16*>(d->pred),
                            d->n_rows, d->no, d->conf_thres, d->class_keep, keys, cap_pow2, counters);
