@@ -149,8 +149,25 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         nms_ms = e0.elapsed_time(e1) / args.profile_passes
-        achieved = conv_flops / (conv_ms * 1e-3) / 1e12
+        conv_bytes = sum(a['bytes'] for a in conv)
+        tflops = conv_flops / (conv_ms * 1e-3) / 1e12
+        gbs = conv_bytes / (conv_ms * 1e-3) / 1e9
+        # which roof binds the convolution work of this model: its FLOP/byte against the machine's
+        hbm_bound = conv_bytes / (PEAK_HBM_GBS * 1e9) >= conv_flops / (PEAK_MFMA_TFLOPS * 1e12)
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'r1_hbm_traffic.json')
+        if os.path.exists(tpath) and args.model == 'yolov5s' and args.batch == 32:
+            with open(tpath) as f:
+                traffic = json.load(f).get('conv_total')  # rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of the same launches
         top = sorted(conv, key=lambda a: -a['ms'])[:6]
+        roofline = {'kernel': 'convolution kernels (conv_igemm / conv_ws1x1 / conv_halo3x3 / focus_conv): all %d launches of one forward'
+                              % len(conv),
+                    'bound': 'hbm' if hbm_bound else 'mfma',
+                    'achieved': round(gbs if hbm_bound else tflops, 2), 'peak': PEAK_HBM_GBS if hbm_bound else PEAK_MFMA_TFLOPS,
+                    'unit': 'GB/s' if hbm_bound else 'TFLOP/s',
+                    'frac': round(gbs / PEAK_HBM_GBS if hbm_bound else tflops / PEAK_MFMA_TFLOPS, 4), 'traffic': traffic,
+                    'bytes_per_forward': conv_bytes, 'flops_per_forward': conv_flops, 'ms_per_forward': round(conv_ms, 4),
+                    'mfma_tflops': round(tflops, 2), 'mfma_frac': round(tflops / PEAK_MFMA_TFLOPS, 4)}
         record = {
             'metric': 'images/sec at 640x640 fp16 (conv fwd+decode+NMS)', 'value': round(value, 1), 'unit': 'images/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_step, 4),
@@ -159,10 +176,7 @@ def main():
                                    'BatchNorm-calibrated, head gain 2.0' % (args.model, args.batch, args.conf, args.iou),
                        'global_batch': args.batch * world, 'parallelism': 'batch shard x%d, detection all_gather' % world,
                        'candidates_per_image': round(cand, 1), 'kept_per_image': round(kept, 1)},
-            'roofline': {'kernel': 'conv_igemm_kernel (all %d conv launches of one forward)' % len(conv), 'bound': 'mfma',
-                         'achieved': round(achieved, 2), 'peak': PEAK_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / PEAK_MFMA_TFLOPS, 4), 'traffic': None,
-                         'flops_per_forward': conv_flops, 'ms_per_forward': round(conv_ms, 4)},
+            'roofline': roofline,
             'stages': {'plan_ms': round(plan_ms, 4), 'conv_ms': round(conv_ms, 4), 'decode_ms': round(dec_ms, 4),
                        'nms_ms': round(nms_ms, 4),
                        'decode_hbm': {'bound': 'hbm', 'achieved': round(dec_bytes / (dec_ms * 1e-3) / 1e9, 1), 'peak': PEAK_HBM_GBS,

@@ -299,8 +299,8 @@ extern "C" int y5_plan_add_decode(y5_plan* p, const y5_decode_desc* d) {
         note_ptr(p, op, 0, d->head);
         note_ptr(p, op, 1, d->x_out);
         note_ptr(p, op, 2, d->z_out);
-        // algorithmic bytes: read the head values once, write z once (fp16)
-        op.bytes = 4.0 * d->batch * d->ny * d->nx * d->na * d->no;
+        // algorithmic bytes: read the head values once, write z (and the permuted raw copy x, when asked for) once, fp16
+        op.bytes = (d->x_out ? 6.0 : 4.0) * d->batch * d->ny * d->nx * d->na * d->no;
         p->ops.push_back(op);
         return Y5_OK;
     });
