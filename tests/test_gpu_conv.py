@@ -144,6 +144,9 @@ VARIANT_SHAPES = [
     (2, 32, 64, 24, 41, 3, 1),
     (1, 64, 136, 19, 23, 3, 1),
     (2, 24, 48, 30, 30, 3, 2),
+    (3, 32, 64, 50, 38, 3, 2),
+    (2, 64, 64, 33, 47, 3, 1),
+    (2, 32, 24, 64, 64, 3, 1),
 ]
 
 
@@ -160,6 +163,8 @@ def test_every_kernel_variant_that_takes_the_shape(dev, shape):
     acc = F.conv2d(x.float(), w.float(), None, s, k // 2)
     ref_bias = F.leaky_relu((acc + bias.view(1, -1, 1, 1)).half().float(), 0.1).half()
     ref_bn = (acc.half().float() * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).half()
+    res = torch.randn(ref_bn.shape, generator=g).half().to(dev)
+    ref_res = (F.leaky_relu(ref_bn.float(), 0.1).half().float() + res.float()).half()
     taken = 0
     for v in range(1, _lib.lib().y5_conv_num_variants() + 1):
         got = run_conv(dev, x, w, bias=bias, slope=0.1, stride=s, variant=v)
@@ -169,6 +174,9 @@ def test_every_kernel_variant_that_takes_the_shape(dev, shape):
         close(got, ref_bias)
         close(run_conv(dev, x, w, scale=scale, shift=shift, stride=s, variant=v), ref_bn)
         close(run_conv(dev, x, w, stride=s, variant=v), acc.half())
+        got = run_conv(dev, x, w, scale=scale, shift=shift, slope=0.1, res=res, stride=s, variant=v)
+        if got is not None:  # some kernel families take no residual input
+            close(got, ref_res)
     assert taken >= 10
 
 

@@ -31,6 +31,16 @@ for _ in range(5):
     assert lib.y5_conv_f16(C.byref(d), st) == 0
 torch.cuda.synchronize()
 n = 65536
+if hasattr(lib, 'y5_debug_stamps3') and var >= 42:
+    buf = np.zeros((n, 8), dtype=np.uint64)
+    assert lib.y5_debug_stamps3(buf.ctypes.data_as(C.c_void_p), n) == 0
+    v = buf[buf[:, 6] > 0].astype(np.float64)
+    nt = v[:, 6].mean()
+    print('variant %d: %d waves, %.2f tiles per workgroup' % (var, len(v), nt))
+    for name, col in (('products', 0), ('stage+fetch', 1), ('epilogue', 2), ('barrier', 3)):
+        print('  %-14s mean %9.0f  per tile %8.1f' % (name, v[:, col].mean(), (v[:, col] / v[:, 6]).mean()))
+    print('  prologue       mean %9.0f;  whole kernel %9.0f' % (v[:, 5].mean(), v[:, 4].mean()))
+    sys.exit(0)
 buf = np.zeros((n, 8), dtype=np.uint64)
 assert lib.y5_debug_stamps(buf.ctypes.data_as(C.c_void_p), n) == 0
 v = buf[buf[:, 6] > 0].astype(np.float64)

@@ -322,6 +322,7 @@ const Variant kVariants[] = {
 constexpr int kNumIgemm = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 constexpr int kNumHalo = 3;  // BN = 128, 64, 32
 constexpr int kNumWs = 3;    // weight-stationary 1x1 kernel, BN = 128, 64, 32
+constexpr int kNumWs3 = 2;   // weight-stationary 3x3 kernel for 32 / 64 input channels, BN = 64, 32
 
 int find_variant(int bm, int bn, int bk, int s) {
     for (int i = 0; i < kNumIgemm; ++i)
@@ -351,7 +352,13 @@ int y5_launch_conv(const y5_conv_desc& d, hipStream_t s) {
     Y5_REQUIRE(d.act == Y5_ACT_NONE || d.act == Y5_ACT_LEAKY, "conv: unknown activation %d", d.act);
     Y5_REQUIRE(d.act == Y5_ACT_NONE || (d.slope > 0.f && d.slope <= 1.f), "conv: LeakyReLU slope %g outside (0, 1]", (double)d.slope);
 
-    Y5_REQUIRE(d.variant >= 0 && d.variant <= kNumIgemm + kNumHalo + kNumWs, "conv: variant %d out of range 0..%d", d.variant, kNumIgemm + kNumHalo + kNumWs);
+    Y5_REQUIRE(d.variant >= 0 && d.variant <= kNumIgemm + kNumHalo + kNumWs + kNumWs3, "conv: variant %d out of range 0..%d", d.variant,
+               kNumIgemm + kNumHalo + kNumWs + kNumWs3);
+    if (d.variant > kNumIgemm + kNumHalo + kNumWs) {
+        int rc = Y5_OK;
+        if (y5_try_conv3x3_ws(d, s, d.variant - kNumIgemm - kNumHalo - kNumWs, &rc)) return rc;
+        return y5_fail(Y5_EINVAL, "conv: the weight-stationary 3x3 variant %d does not apply to this shape", d.variant);
+    }
     if (d.variant > kNumIgemm + kNumHalo) {
         int rc = Y5_OK;
         if (y5_try_conv_ws1x1(d, s, d.variant - kNumIgemm - kNumHalo, &rc)) return rc;
@@ -404,4 +411,4 @@ int y5_launch_conv(const y5_conv_desc& d, hipStream_t s) {
     return kVariants[v].launch(a, d.ksize, direct, s);
 }
 
-int y5_conv_variant_count() { return kNumIgemm + kNumHalo + kNumWs; }
+int y5_conv_variant_count() { return kNumIgemm + kNumHalo + kNumWs + kNumWs3; }

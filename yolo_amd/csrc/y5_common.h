@@ -41,6 +41,7 @@ int y5_launch_conv(const y5_conv_desc& d, hipStream_t s);
 // 3x3 stride-1 halo-tile kernel (conv_halo.hip): returns 1 and sets *rc when it took the convolution.
 int y5_try_conv_halo(const y5_conv_desc& d, hipStream_t s, int force_bn, int* rc);
 int y5_try_conv_ws1x1(const y5_conv_desc& d, hipStream_t s, int which, int* rc);
+int y5_try_conv3x3_ws(const y5_conv_desc& d, hipStream_t s, int which, int* rc);
 int y5_conv_variant_count();
 // Focus gather + 3x3 convolution from the NCHW image (conv_focus.hip); d.x is the image, d.cin its 3 channels.
 int y5_launch_focus_conv(const y5_conv_desc& d, hipStream_t s);
