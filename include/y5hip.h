@@ -151,6 +151,10 @@ typedef struct y5_decode_desc {
 } y5_decode_desc;
 
 int y5_detect_decode_f16(const y5_decode_desc* d, y5_stream_t stream);
+/* The same for n_levels (<= Y5_MAX_LEVELS) pyramid levels in ONE launch: the loop `for i in range(self.nl)` of
+ * Detect.forward  models/yolo.py:31-46.  Results are identical to n_levels separate calls. */
+#define Y5_MAX_LEVELS 4
+int y5_detect_decode_multi_f16(const y5_decode_desc* levels, int n_levels, y5_stream_t stream);
 
 /* y[i] = fp16(sigmoid(x[i])) for n fp16 values, the elementwise op of Detect.forward (x[i].sigmoid(), models/yolo.py:41)
  * exactly as the decode kernel evaluates it.  libm = 0: the kernel's exp2/reciprocal form; libm = 1: 1/(1+expf(-x)) with
@@ -228,6 +232,7 @@ int y5_plan_add_upsample2x(y5_plan* p, const void* x, int x_ld, void* y, int y_l
                            int mode);
 int y5_plan_add_copy_channels(y5_plan* p, const void* x, int x_ld, void* y, int y_ld, int64_t pixels, int c);
 int y5_plan_add_decode(y5_plan* p, const y5_decode_desc* d);
+int y5_plan_add_decode_multi(y5_plan* p, const y5_decode_desc* levels, int n_levels);
 int y5_plan_num_ops(const y5_plan* p);
 /* Replay all ops on `stream`. ext (host array of n_ext device pointers) supplies the external slots. */
 int y5_plan_run(y5_plan* p, void* const* ext, int n_ext, y5_stream_t stream);
@@ -243,6 +248,7 @@ int y5_plan_profile(y5_plan* p, void* const* ext, int n_ext, y5_stream_t stream,
 #define Y5_OP_DECODE 6
 #define Y5_OP_MAXPOOL_CASCADE 7
 #define Y5_OP_FOCUS_CONV 8
+#define Y5_OP_DECODE_MULTI 9
 int y5_plan_op_info(const y5_plan* p, int i, int* kind, double* flops, double* bytes);
 
 #ifdef __cplusplus

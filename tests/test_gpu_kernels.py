@@ -107,6 +107,40 @@ def test_decode_bit_exact_against_reference_fixture(dev, tag):
     assert torch.equal(zo.cpu().view(torch.int16), zg.view(torch.int16))
 
 
+@pytest.mark.parametrize('tag', ['nc80_64x96', 'nc5_128x128', 'nc1_odd'])
+def test_decode_all_levels_in_one_launch_against_reference_fixture(dev, tag):
+    """y5_detect_decode_multi_f16 (what the engine records) must give the fixture's z and x tensors bit for bit."""
+    lib = _lib.lib()
+    z = util.golden('decode_' + tag)
+    zg = torch.from_numpy(z['z'])
+    no = zg.shape[2]
+    zo = torch.zeros(zg.shape, dtype=torch.float16, device=dev)
+    levels = (_lib.DecodeDesc * 3)()
+    keep, xs, row0 = [], [], 0
+    for i in range(3):
+        raw = torch.from_numpy(z['raw%d' % i]).to(dev)
+        B, c, ny, nx = raw.shape
+        na, ld = c // no, (c + 7) // 8 * 8
+        head = nhwc(raw, ld, dev)
+        xo = torch.zeros(B, na, ny, nx, no, dtype=torch.float16, device=dev)
+        keep.append(head)
+        xs.append(xo)
+        d = levels[i]
+        d.head, d.head_ld, d.x_out, d.z_out = head.data_ptr(), ld, xo.data_ptr(), zo.data_ptr()
+        d.batch, d.ny, d.nx, d.na, d.no = B, ny, nx, na, no
+        d.z_rows_total, d.z_row0, d.stride = zg.shape[1], row0, float(z['stride'][i])
+        wh = z['anchor_grid'][i].reshape(-1, 2)
+        for a in range(na):
+            d.anchor_wh[2 * a], d.anchor_wh[2 * a + 1] = float(wh[a, 0]), float(wh[a, 1])
+        row0 += na * ny * nx
+    _lib.check(lib.y5_detect_decode_multi_f16(levels, 3, _lib.current_stream()))
+    torch.cuda.synchronize()
+    for i in range(3):
+        assert torch.equal(xs[i].cpu(), torch.from_numpy(z['x%d' % i]))
+    assert torch.equal(zo.cpu().view(torch.int16), zg.view(torch.int16))
+    assert lib.y5_detect_decode_multi_f16(levels, 5, _lib.current_stream()) == _lib.EINVAL
+
+
 def test_decode_full_size_level_against_oracle(dev):
     g = torch.Generator().manual_seed(0)
     raw = (torch.randn(2, 255, 80, 80, generator=g) * 4).half()

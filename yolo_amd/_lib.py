@@ -10,9 +10,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liby5hip.so')
 
 Y5_MAX_ANCHORS = 8
+Y5_MAX_LEVELS = 4
 ACT_NONE, ACT_LEAKY = 0, 1
 OK, EINVAL, EHIP, ENOMEM, EWORKSPACE = 0, -1, -2, -3, -4  # y5_status in include/y5hip.h
-OP_NAMES = {8: 'focus_conv', 1: 'conv', 2: 'pack', 3: 'maxpool', 4: 'upsample', 5: 'copy', 6: 'decode', 7: 'maxpool'}
+OP_NAMES = {8: 'focus_conv', 9: 'decode', 1: 'conv', 2: 'pack', 3: 'maxpool', 4: 'upsample', 5: 'copy', 6: 'decode', 7: 'maxpool'}
 
 
 class ConvDesc(C.Structure):
@@ -56,6 +57,7 @@ SIGNATURES = {
     'y5_upsample2x_f16': (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _s]),
     'y5_copy_channels_f16': (_i, [_p, _i, _p, _i, C.c_int64, _i, _s]),
     'y5_detect_decode_f16': (_i, [C.POINTER(DecodeDesc), _s]),
+    'y5_detect_decode_multi_f16': (_i, [C.POINTER(DecodeDesc), C.c_int, _s]),
     'y5_sigmoid_f16': (_i, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, _s]),
     'y5_nms_workspace_bytes': (C.c_size_t, [_i, _i]),
     'y5_nms_batched': (_i, [C.POINTER(NmsDesc), _s]),
@@ -71,6 +73,7 @@ SIGNATURES = {
     'y5_plan_add_upsample2x': (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _i]),
     'y5_plan_add_copy_channels': (_i, [_p, _p, _i, _p, _i, C.c_int64, _i]),
     'y5_plan_add_decode': (_i, [_p, C.POINTER(DecodeDesc)]),
+    'y5_plan_add_decode_multi': (_i, [_p, C.POINTER(DecodeDesc), C.c_int]),
     'y5_plan_num_ops': (_i, [_p]),
     'y5_plan_run': (_i, [_p, C.POINTER(_p), _i, _s]),
     'y5_plan_profile': (_i, [_p, C.POINTER(_p), _i, _s, C.POINTER(C.c_float), _i]),

@@ -74,6 +74,10 @@ extern "C" int y5_detect_decode_f16(const y5_decode_desc* d, y5_stream_t stream)
     return y5_launch_decode(*d, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int y5_detect_decode_multi_f16(const y5_decode_desc* levels, int n_levels, y5_stream_t stream) {
+    return y5_launch_decode_multi(levels, n_levels, static_cast<hipStream_t>(stream));
+}
+
 // ------------------------------------------------------------------------------------------
 // launch plan
 // ------------------------------------------------------------------------------------------
@@ -94,6 +98,7 @@ struct Op {
     int kind = 0;
     y5_conv_desc conv{};
     y5_decode_desc dec{};
+    y5_decode_desc decm[Y5_MAX_LEVELS] = {};  // Y5_OP_DECODE_MULTI: i[0] levels
     // generic pointwise arguments
     const void* px = nullptr;
     void* py = nullptr;
@@ -135,6 +140,14 @@ bool set_ptr(Op& op, int field, const void* v) {
             else if (field == 2) op.conv.res = v;
             else return false;
             return true;
+        case Y5_OP_DECODE_MULTI: {
+            const int l = field / 3, f = field % 3;
+            if (l >= op.i[0]) return false;
+            if (f == 0) op.decm[l].head = v;
+            else if (f == 1) op.decm[l].x_out = nv;
+            else op.decm[l].z_out = nv;
+            return true;
+        }
         case Y5_OP_DECODE:
             if (field == 0) op.dec.head = v;
             else if (field == 1) op.dec.x_out = nv;
@@ -160,6 +173,7 @@ int run_op(const Op& op, hipStream_t s) {
         case Y5_OP_UPSAMPLE: return y5_launch_upsample2x(op.px, op.i[0], op.py, op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6], s);
         case Y5_OP_COPY: return y5_launch_copy_channels(op.px, op.i[0], op.py, op.i[1], op.pixels, op.i[2], s);
         case Y5_OP_DECODE: return y5_launch_decode(op.dec, s);
+        case Y5_OP_DECODE_MULTI: return y5_launch_decode_multi(op.decm, op.i[0], s);
     }
     return y5_fail(Y5_EINVAL, "plan: unknown op kind %d", op.kind);
 }
@@ -301,6 +315,26 @@ extern "C" int y5_plan_add_decode(y5_plan* p, const y5_decode_desc* d) {
         note_ptr(p, op, 2, d->z_out);
         // algorithmic bytes: read the head values once, write z (and the permuted raw copy x, when asked for) once, fp16
         op.bytes = (d->x_out ? 6.0 : 4.0) * d->batch * d->ny * d->nx * d->na * d->no;
+        p->ops.push_back(op);
+        return Y5_OK;
+    });
+}
+
+extern "C" int y5_plan_add_decode_multi(y5_plan* p, const y5_decode_desc* levels, int n_levels) {
+    Y5_REQUIRE(p && levels, "plan_add_decode_multi: null argument");
+    Y5_REQUIRE(n_levels >= 1 && n_levels <= Y5_MAX_LEVELS, "plan_add_decode_multi: %d levels out of range 1..%d", n_levels, Y5_MAX_LEVELS);
+    return guarded([&]() {
+        Op op;
+        op.kind = Y5_OP_DECODE_MULTI;
+        op.i[0] = n_levels;
+        for (int l = 0; l < n_levels; ++l) {
+            const y5_decode_desc& d = levels[l];
+            op.decm[l] = d;
+            note_ptr(p, op, 3 * l + 0, d.head);
+            note_ptr(p, op, 3 * l + 1, d.x_out);
+            note_ptr(p, op, 3 * l + 2, d.z_out);
+            op.bytes += (d.x_out ? 6.0 : 4.0) * d.batch * d.ny * d.nx * d.na * d.no;
+        }
         p->ops.push_back(op);
         return Y5_OK;
     });

@@ -51,13 +51,11 @@ __device__ __forceinline__ f16 decode_one(f16 raw, int o, float gx, float gy, fl
     return (f16)((float)sq * (o == 2 ? aw : ah));           // * fp16 anchor_grid, fp16 result
 }
 
+// One workgroup's work: tile `block` (TP pixels of one image) of the level described by a.
 template <bool VEC>
-__global__ __launch_bounds__(kThreads) void detect_decode_kernel(const DecodeArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    f16* tile = reinterpret_cast<f16*>(smem_raw);
-
-    const int b = blockIdx.x / a.tiles_per_image;
-    const int tp = blockIdx.x - b * a.tiles_per_image;
+__device__ __forceinline__ void decode_tile(const DecodeArgs& a, int block, f16* tile) {
+    const int b = block / a.tiles_per_image;
+    const int tp = block - b * a.tiles_per_image;
     const int npix_img = a.ny * a.nx;
     const int pix0 = tp * TP;
     const int np = min(TP, npix_img - pix0);
@@ -128,6 +126,28 @@ __global__ __launch_bounds__(kThreads) void detect_decode_kernel(const DecodeArg
     }
 }
 
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void detect_decode_kernel(const DecodeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    decode_tile<VEC>(a, blockIdx.x, reinterpret_cast<f16*>(smem_raw));
+}
+
+// All pyramid levels in one launch: the small levels (a few hundred workgroups) run beside the large one instead
+// of each paying its own ramp-up and tail.
+struct DecodeMultiArgs {
+    DecodeArgs lv[Y5_MAX_LEVELS];
+    int first_block[Y5_MAX_LEVELS + 1];  // workgroups [first_block[l], first_block[l+1]) belong to level l
+    int n;
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void detect_decode_multi_kernel(const DecodeMultiArgs m) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    int l = 0;
+    while (l + 1 < m.n && (int)blockIdx.x >= m.first_block[l + 1]) ++l;
+    decode_tile<VEC>(m.lv[l], blockIdx.x - m.first_block[l], reinterpret_cast<f16*>(smem_raw));
+}
+
 }  // namespace
 
 int y5_launch_sigmoid(const void* x, void* y, long long n, int libm, hipStream_t s) {
@@ -139,7 +159,10 @@ int y5_launch_sigmoid(const void* x, void* y, long long n, int libm, hipStream_t
     return Y5_OK;
 }
 
-int y5_launch_decode(const y5_decode_desc& d, hipStream_t s) {
+namespace {
+
+// Validates one level and fills its kernel arguments; *vec says whether the 16-byte store path applies.
+int prepare_level(const y5_decode_desc& d, DecodeArgs& a, size_t* lds_bytes, bool* vec) {
     Y5_REQUIRE(d.head && d.z_out, "decode: null pointer");
     Y5_REQUIRE(d.batch > 0 && d.ny > 0 && d.nx > 0, "decode: empty tensor");
     Y5_REQUIRE(d.na >= 1 && d.na <= Y5_MAX_ANCHORS, "decode: na %d out of range 1..%d", d.na, Y5_MAX_ANCHORS);
@@ -149,10 +172,9 @@ int y5_launch_decode(const y5_decode_desc& d, hipStream_t s) {
     Y5_REQUIRE(d.head_ld % 8 == 0 && d.head_ld >= lds_ld, "decode: head_ld %d must be a multiple of 8 >= %d", d.head_ld, lds_ld);
     Y5_REQUIRE(y5_aligned16(d.head), "decode: head must be 16-byte aligned");
     Y5_REQUIRE(d.z_row0 >= 0 && (long long)d.z_row0 + (long long)d.na * d.ny * d.nx <= d.z_rows_total, "decode: rows %d..+%d exceed z_rows_total %d", d.z_row0, d.na * d.ny * d.nx, d.z_rows_total);
-    const size_t lds_bytes = ((size_t)TP * lds_ld + (size_t)(TP + 1) * d.na * 4) * sizeof(f16);  // staged pixels + decoded box slots
-    Y5_REQUIRE(lds_bytes <= 64 * 1024, "decode: na*no = %d too large for the staging tile", chans);
+    *lds_bytes = ((size_t)TP * lds_ld + (size_t)(TP + 1) * d.na * 4) * sizeof(f16);  // staged pixels + decoded box slots
+    Y5_REQUIRE(*lds_bytes <= 64 * 1024, "decode: na*no = %d too large for the staging tile", chans);
 
-    DecodeArgs a;
     a.head = static_cast<const f16*>(d.head);
     a.x_out = static_cast<f16*>(d.x_out);
     a.z_out = static_cast<f16*>(d.z_out);
@@ -163,16 +185,53 @@ int y5_launch_decode(const y5_decode_desc& d, hipStream_t s) {
     a.lds_ld = lds_ld;
     a.stride = d.stride;
     for (int i = 0; i < 2 * Y5_MAX_ANCHORS; ++i) a.anchor_wh[i] = d.anchor_wh[i];
+    Y5_REQUIRE((long long)a.tiles_per_image * d.batch < 0x7fffffffLL, "decode: too many tiles");
 
     // 16-byte stores need every per-anchor run to start on a multiple of 8 elements in both tensors:
     // runs start at ((b*na + an)*npix + pix0)*no and (b*rows + row0 + an*npix + pix0)*no with pix0 % 64 == 0.
-    const bool vec = (((long long)npix * d.no) % 8 == 0) && (((long long)d.z_rows_total * d.no) % 8 == 0) &&
-                     (((long long)d.z_row0 * d.no) % 8 == 0) && y5_aligned16(d.z_out) && y5_aligned16(d.x_out);
+    *vec = (((long long)npix * d.no) % 8 == 0) && (((long long)d.z_rows_total * d.no) % 8 == 0) &&
+           (((long long)d.z_row0 * d.no) % 8 == 0) && y5_aligned16(d.z_out) && y5_aligned16(d.x_out);
+    return Y5_OK;
+}
+
+}  // namespace
+
+int y5_launch_decode(const y5_decode_desc& d, hipStream_t s) {
+    DecodeArgs a;
+    size_t lds_bytes = 0;
+    bool vec = false;
+    if (int rc = prepare_level(d, a, &lds_bytes, &vec)) return rc;
     const dim3 grid((unsigned)(a.tiles_per_image * d.batch));
     if (vec)
         hipLaunchKernelGGL(detect_decode_kernel<true>, grid, dim3(kThreads), lds_bytes, s, a);
     else
         hipLaunchKernelGGL(detect_decode_kernel<false>, grid, dim3(kThreads), lds_bytes, s, a);
     Y5_LAUNCH_CHECK("detect_decode_kernel");
+    return Y5_OK;
+}
+
+int y5_launch_decode_multi(const y5_decode_desc* d, int n, hipStream_t s) {
+    Y5_REQUIRE(d && n >= 1 && n <= Y5_MAX_LEVELS, "decode_multi: %d levels out of range 1..%d", n, Y5_MAX_LEVELS);
+    DecodeMultiArgs m{};
+    m.n = n;
+    size_t lds_max = 0;
+    bool vec_all = true;
+    long long blocks = 0;
+    for (int l = 0; l < n; ++l) {
+        size_t lds_bytes = 0;
+        bool vec = false;
+        if (int rc = prepare_level(d[l], m.lv[l], &lds_bytes, &vec)) return rc;
+        vec_all = vec_all && vec;
+        if (lds_bytes > lds_max) lds_max = lds_bytes;
+        m.first_block[l] = (int)blocks;
+        blocks += (long long)m.lv[l].tiles_per_image * d[l].batch;
+        Y5_REQUIRE(blocks < 0x7fffffffLL, "decode_multi: too many tiles");
+    }
+    m.first_block[n] = (int)blocks;
+    if (vec_all)
+        hipLaunchKernelGGL(detect_decode_multi_kernel<true>, dim3((unsigned)blocks), dim3(kThreads), lds_max, s, m);
+    else
+        hipLaunchKernelGGL(detect_decode_multi_kernel<false>, dim3((unsigned)blocks), dim3(kThreads), lds_max, s, m);
+    Y5_LAUNCH_CHECK("detect_decode_multi_kernel");
     return Y5_OK;
 }

@@ -53,4 +53,5 @@ int y5_launch_upsample2x(const void* x, int x_ld, void* y, int y_ld, int batch, 
                          hipStream_t s);
 int y5_launch_copy_channels(const void* x, int x_ld, void* y, int y_ld, int64_t pixels, int c, hipStream_t s);
 int y5_launch_decode(const y5_decode_desc& d, hipStream_t s);
+int y5_launch_decode_multi(const y5_decode_desc* d, int n, hipStream_t s);
 int y5_launch_sigmoid(const void* x, void* y, long long n, int libm, hipStream_t s);

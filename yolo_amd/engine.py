@@ -602,6 +602,8 @@ class Plan:
             _lib.check(self.lib.y5_plan_bind_slot(self.handle, 2 + i, t.data_ptr(), t.numel() * 2))
         row0 = 0
         anchor_grid = m.anchor_grid.detach().float().cpu().view(m.nl, na, 2)
+        fused = len(feats) <= _lib.Y5_MAX_LEVELS and os.environ.get('Y5_DECODE_FUSE', '1') != '0'
+        levels = (_lib.DecodeDesc * len(feats))()
         for i, f in enumerate(feats):
             conv = m.m[i]
             if conv.out_channels != na * no:
@@ -617,9 +619,15 @@ class Plan:
             for a in range(na):
                 d.anchor_wh[2 * a] = float(anchor_grid[i, a, 0])
                 d.anchor_wh[2 * a + 1] = float(anchor_grid[i, a, 1])
-            _lib.check(self.lib.y5_plan_add_decode(self.handle, C.byref(d)))
-            self.labels.append('detect.decode%d @%dx%d' % (i, f.h, f.w))
+            if fused:
+                C.memmove(C.byref(levels[i]), C.byref(d), C.sizeof(_lib.DecodeDesc))
+            else:
+                _lib.check(self.lib.y5_plan_add_decode(self.handle, C.byref(d)))
+                self.labels.append('detect.decode%d @%dx%d' % (i, f.h, f.w))
             row0 += rows[i]
+        if fused:  # every level's head conv is recorded by now: one launch decodes them all
+            _lib.check(self.lib.y5_plan_add_decode_multi(self.handle, levels, len(feats)))
+            self.labels.append('detect.decode all %d levels' % len(feats))
 
     # ------------------------------------------------------------------ execution
     def _ext(self, x, z, xs):
