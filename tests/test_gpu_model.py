@@ -29,7 +29,8 @@ def agree(got, ref, frac_exact, rel=4e-3):
 
 
 @pytest.mark.parametrize('cfg,fuse,shape', [('yolov5s', False, (2, 3, 64, 64)), ('yolov5s', True, (1, 3, 128, 96)),
-                                            ('yolov5s_ori', False, (2, 3, 64, 64)), ('yolov5s_ori', True, (2, 3, 96, 160))])
+                                            ('yolov5s_ori', False, (2, 3, 64, 64)), ('yolov5s_ori', True, (2, 3, 96, 160)),
+                                            ('yolov5m', True, (1, 3, 64, 96)), ('yolov5x', True, (1, 3, 64, 64))])
 def test_forward_against_oracle(dev, cfg, fuse, shape):
     model = util.build_model(cfg)
     util.randomize_bn(model, 11)
