@@ -76,7 +76,7 @@ __device__ __forceinline__ void wait_vm_and_barrier(int n) {
     case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
     switch (n) {
         Y5_WAIT_CASE(1) Y5_WAIT_CASE(2) Y5_WAIT_CASE(3) Y5_WAIT_CASE(4) Y5_WAIT_CASE(5) Y5_WAIT_CASE(6)
-        Y5_WAIT_CASE(7) Y5_WAIT_CASE(8) Y5_WAIT_CASE(9) Y5_WAIT_CASE(10) Y5_WAIT_CASE(12) Y5_WAIT_CASE(16)
+        Y5_WAIT_CASE(7) Y5_WAIT_CASE(8) Y5_WAIT_CASE(9) Y5_WAIT_CASE(10) Y5_WAIT_CASE(11) Y5_WAIT_CASE(12) Y5_WAIT_CASE(16)
         default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
     }
 #undef Y5_WAIT_CASE

@@ -2,10 +2,10 @@
 //
 // The im2col kernel in conv_igemm.hip re-gathers every input pixel nine times (once per tap).  Here a
 // workgroup owns an 8x16 block of output pixels (x BN channels): for each chunk of 32 input channels it
-// brings the 10x18 input halo into LDS ONCE by global->LDS DMA, and the nine taps are nine MFMA steps that
-// read the same LDS image at shifted pixel offsets.  Only the 32-channel weight tile of the step is streamed
+// brings the 10x18 input halo into LDS ONCE by global->LDS DMA, and the nine taps read the same LDS image at
+// shifted pixel offsets.  A step is one kernel row (three taps): its three 32-channel weight tiles are streamed
 // per step (3-deep ring, two steps ahead); the next chunk's halo is fetched one chunk ahead into the second
-// halo buffer.  All DMA is counted by hand (s_waitcnt vmcnt) with one barrier per step.
+// halo buffer.  All DMA is counted by hand (s_waitcnt vmcnt) with one barrier per step, i.e. three per chunk.
 //
 // LDS image: pixel records of 64 bytes (32 channels), halo rows at a pitch of 32 records so that the two
 // 16-pixel rows an MFMA operand covers are 32 records apart; with the 16-byte chunk index XOR-ed with
@@ -38,8 +38,8 @@ __global__ __launch_bounds__(256) void conv_halo3x3_kernel(const ConvArgs a) {
     constexpr int B_CH = (BN * 4 + 255) / 256;
     constexpr int EP = BN * 2 + 16;
     constexpr int RING0 = 2 * HALO_BYTES;
-    constexpr int SMEM = (RING0 + SB * BT_BYTES > HBM_ * EP) ? RING0 + SB * BT_BYTES : HBM_ * EP;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
+    constexpr int ST_BYTES = 3 * BT_BYTES;           // one ring stage: the three taps of a kernel row
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void conv_halo3x3_kernel(const ConvArgs a) {
     const f16* wrow[B_CH];
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) wrow[i] = a.w + (size_t)(n0 + (bload ? row0 : 0) + 64 * i) * a.w_ld + kcb * 8;
-    const int lpsb = bload ? B_CH : 0;
+    const int lpsb = bload ? 3 * B_CH : 0;  // weight DMA instructions this wave issues per step
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
     auto issue_halo = [&](int ci, int buf) {
@@ -87,14 +87,17 @@ __global__ __launch_bounds__(256) void conv_halo3x3_kernel(const ConvArgs a) {
             dma16(src, lds0 + buf * HALO_BYTES + ((j >> 1) * PITCH + (j & 1) * 16) * REC);
         }
     };
-    auto issue_b = [&](int ci, int tap, int stage) {
+    auto issue_b = [&](int ci, int r, int stage) {
         if (bload) {
             const bool cvalid = ci * CK + kcb * 8 < a.Cin;
-            const int koff = tap * a.Cin + ci * CK;
 #pragma unroll
-            for (int i = 0; i < B_CH; ++i)
-                dma16(cvalid ? (const void*)(wrow[i] + koff) : (const void*)y5_zero_page,
-                      lds0 + RING0 + stage * BT_BYTES + i * 4096 + wave * 1024);
+            for (int q = 0; q < 3; ++q) {
+                const int koff = (r * 3 + q) * a.Cin + ci * CK;
+#pragma unroll
+                for (int i = 0; i < B_CH; ++i)
+                    dma16(cvalid ? (const void*)(wrow[i] + koff) : (const void*)y5_zero_page,
+                          lds0 + RING0 + stage * ST_BYTES + q * BT_BYTES + i * 4096 + wave * 1024);
+            }
         }
     };
 
@@ -113,41 +116,44 @@ __global__ __launch_bounds__(256) void conv_halo3x3_kernel(const ConvArgs a) {
     for (int i = 0; i < RM; ++i) arec[i] = (wm * (WTM / 16) + 2 * i + dy) * PITCH + tx;
     const int swb = (lr >> 2) & 3;
 
-    const int total = a.nchunks * 9;
+    const int total = a.nchunks * 3;
     issue_halo(0, 0);
     issue_b(0, 0, 0);
     if (total > 1) issue_b(0, 1, 1);
     int it = 0;
     for (int ci = 0; ci < a.nchunks; ++ci) {
         const bool more = ci + 1 < a.nchunks;
-        for (int tap = 0; tap < 9; ++tap, ++it) {
+        for (int r = 0; r < 3; ++r, ++it) {
+            // younger than what this step reads: the next step's weights and, in rows 1 and 2, the next chunk's halo
             int allowed = (it + 1 < total) ? lpsb : 0;
-            if (more && (tap == 1 || tap == 2)) allowed += HALO_DMA;
+            if (more && r >= 1) allowed += HALO_DMA;
             wait_vm_and_barrier(allowed);
             if (it + 2 < total) {
                 const int nx = it + 2;
-                const int nci = nx >= (ci + 1) * 9 ? ci + 1 : ci;
-                issue_b(nci, nx - nci * 9, nx % SB);
+                const int nci = nx >= (ci + 1) * 3 ? ci + 1 : ci;
+                issue_b(nci, nx - nci * 3, nx % SB);
             }
-            if (tap == 0 && more) issue_halo(ci + 1, (ci + 1) & 1);
-            const int r = (tap * 11) >> 5, q = tap - 3 * r;
-            const unsigned char* Hb = smem + (ci & 1) * HALO_BYTES + (r * PITCH + q) * REC;
-            const unsigned char* B = smem + RING0 + (it % SB) * BT_BYTES;
-            const int swa = ((tx + q) >> 2) & 3;
+            if (r == 0 && more) issue_halo(ci + 1, (ci + 1) & 1);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                f16x8 xf[RM], wf[RN];
+            for (int q = 0; q < 3; ++q) {
+                const unsigned char* Hb = smem + (ci & 1) * HALO_BYTES + (r * PITCH + q) * REC;
+                const unsigned char* B = smem + RING0 + (it % SB) * ST_BYTES + q * BT_BYTES;
+                const int swa = ((tx + q) >> 2) & 3;
 #pragma unroll
-                for (int i = 0; i < RM; ++i)
-                    xf[i] = *reinterpret_cast<const f16x8*>(Hb + arec[i] * REC + (((2 * ks + lh) ^ swa) << 4));
-#pragma unroll
-                for (int j = 0; j < RN; ++j)
-                    wf[j] = *reinterpret_cast<const f16x8*>(B + (wn * WTN + j * 32 + lr) * REC + (((2 * ks + lh) ^ swb) << 4));
-#pragma unroll
-                for (int j = 0; j < RN; ++j)
+                for (int ks = 0; ks < 2; ++ks) {
+                    f16x8 xf[RM], wf[RN];
 #pragma unroll
                     for (int i = 0; i < RM; ++i)
-                        acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], xf[i], acc[j][i], 0, 0, 0);
+                        xf[i] = *reinterpret_cast<const f16x8*>(Hb + arec[i] * REC + (((2 * ks + lh) ^ swa) << 4));
+#pragma unroll
+                    for (int j = 0; j < RN; ++j)
+                        wf[j] = *reinterpret_cast<const f16x8*>(B + (wn * WTN + j * 32 + lr) * REC + (((2 * ks + lh) ^ swb) << 4));
+#pragma unroll
+                    for (int j = 0; j < RN; ++j)
+#pragma unroll
+                        for (int i = 0; i < RM; ++i)
+                            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], xf[i], acc[j][i], 0, 0, 0);
+                }
             }
         }
     }
@@ -196,7 +202,14 @@ int launch_halo(ConvArgs a, hipStream_t s) {
     const long long total = (long long)a.tiles_x * a.tiles_y * (a.M / ((long long)a.H * a.W)) * a.tiles_n;
     if (total <= 0 || total > 0x7fffffffLL) return y5_fail(Y5_EINVAL, "conv: tile count %lld out of range", total);
     a.tiles_total = (int)total;
-    hipLaunchKernelGGL((conv_halo3x3_kernel<BN, WM, WN>), dim3((unsigned)total), dim3(256), 0, s, a);
+    constexpr int ring = 2 * HALO_BYTES + 3 * 3 * BN * REC, ep = HBM_ * (BN * 2 + 16);
+    constexpr int smem = ring > ep ? ring : ep;
+    static bool attr_set = false;  // per process
+    if (!attr_set) {
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo3x3_kernel<BN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_halo3x3_kernel<BN, WM, WN>), dim3((unsigned)total), dim3(256), smem, s, a);
     Y5_LAUNCH_CHECK("conv_halo3x3_kernel");
     return Y5_OK;
 }

@@ -39,8 +39,12 @@ struct IgemmCfg {
     static constexpr int SMEM = (S * STAGE_BYTES > BM * EP) ? S * STAGE_BYTES : BM * EP;
 };
 
-template <int BM, int BN, int WM, int WN, int KS, int S, int BK, bool DIRECT>
+// UT ("uniform tap", KS = 3 with Cin a multiple of BK): every chunk of a K-step belongs to the same tap, so the tap's
+// pixel offset is one wave-uniform number and a thread only keeps, per staged row, the pointer to its pixel at tap
+// (0, 0) and nine validity bits -- a DMA instruction then costs ~8 instructions of address work instead of ~20.
+template <int BM, int BN, int WM, int WN, int KS, int S, int BK, bool DIRECT, bool UT = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs a) {
+    static_assert(!UT || (KS == 3 && !DIRECT), "uniform-tap addressing is for 3x3 convolutions");
     constexpr int NW = WM * WN, NT = 64 * NW;
     static_assert(NW == 4 || NW == 8, "four or eight waves per workgroup");
     static_assert(BK == 32 || BK == 64, "K-step is 32 or 64");
@@ -95,6 +99,33 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
             xrow[i] = a.x + (size_t)b * a.H * a.W * a.x_ld;
         }
     }
+    // UT / DIRECT: running source pointer per staged row (UT: pixel of tap (0,0) -- possibly outside the image, never
+    // dereferenced then -- plus this thread's chunk; DIRECT: the pixel's current K position) and validity bits
+    const f16* acur[A_CH];
+    unsigned vmask[A_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        acur[i] = nullptr;
+        vmask[i] = 0;
+        if (UT) {
+            acur[i] = xrow[i] + ((ptrdiff_t)hi0[i] * a.W + wi0[i]) * a.x_ld + kc * 8;
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                const int hi = hi0[i] + tp / 3, wi = wi0[i] + tp % 3;
+                if (mvalid[i] && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W) vmask[i] |= 1u << tp;
+            }
+        } else if (DIRECT) {
+            acur[i] = xrow[i] + kc * 8;
+        }
+    }
+    // The zero page's address, pinned in registers: left to itself the compiler re-derives it (a scalar load and a
+    // wait) in every K-step.
+    const void* zpage = y5_zero_page;
+    asm volatile("" : "+v"(zpage));
+    int ut_tap = 0, ut_c0 = 0;  // wave-uniform: tap and first channel of the next K-step to fetch
+    ptrdiff_t ut_off = 0;       // ... and that tap's element offset from tap (0, 0), its validity bit
+    unsigned ut_bit = 0;
+
     const bool bload = wave < B_WAVES;  // wave-uniform
     const f16* wptr[B_CH];
 #pragma unroll
@@ -114,6 +145,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
     int st_r = 0, st_q = 0;
     bool st_kvalid = false;
     auto step_begin = [&]() {
+        if (UT) {
+            const int r = (ut_tap * 11) >> 5, q = ut_tap - 3 * r;
+            ut_off = ((ptrdiff_t)r * a.W + q) * a.x_ld + ut_c0;
+            ut_bit = 1u << ut_tap;
+            return;
+        }
         if (KS > 1) {
             st_r = (tap * 11) >> 5;  // tap / 3 for tap < 32
             st_q = tap - 3 * st_r;
@@ -124,12 +161,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
         if (p < A_CH) {
             const int i = p;
             const void* src;
-            if (DIRECT) {
-                src = (st_kvalid && mvalid[i]) ? (const void*)(xrow[i] + kpos) : (const void*)y5_zero_page;
+            if (UT) {
+                src = (vmask[i] & ut_bit) ? (const void*)(acur[i] + ut_off) : zpage;
+            } else if (DIRECT) {
+                src = (st_kvalid && mvalid[i]) ? (const void*)acur[i] : zpage;
+                acur[i] += BK;
             } else {
                 const int hi = hi0[i] + st_r, wi = wi0[i] + st_q;
                 const bool ok = st_kvalid && mvalid[i] && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-                src = ok ? (const void*)(xrow[i] + (size_t)(hi * a.W + wi) * a.x_ld + cch) : (const void*)y5_zero_page;
+                src = ok ? (const void*)(xrow[i] + (size_t)(hi * a.W + wi) * a.x_ld + cch) : zpage;
             }
             dma16(src, lds0 + stage * STAGE_BYTES + wave * 1024 + i * PIECE);
         } else if (bload) {
@@ -139,6 +179,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
         }
     };
     auto step_end = [&]() {
+        if (UT) {
+            ut_c0 += BK;
+            if (ut_c0 >= a.Cin) {
+                ut_c0 = 0;
+                ++ut_tap;
+            }
+            return;
+        }
         kpos += BK;
         if (KS > 1) {
             cch += BK;
@@ -187,6 +235,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
         Y5_STAMP(s2);
         const unsigned char* A = smem + (kt % S) * STAGE_BYTES;
         const unsigned char* B = A + BM * ROW_BYTES;
+#ifdef Y5_STAMPS
+        if (a.res_ld == -12345) continue;  // diagnostic: staging only, no LDS reads and no MFMAs
+#endif
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             const int coff = ((2 * ks + lh) ^ sw) << 4;
@@ -281,13 +332,17 @@ int launch_tile(const ConvArgs& a0, int ksize, bool direct, hipStream_t s) {
     if (!attr_set) {
         Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, 3, S, BK, false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, 3, S, BK, false, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
         Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, 1, S, BK, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
         Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, 1, S, BK, false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
         attr_set = true;
     }
-    if (ksize == 3)
+    if (ksize == 3 && a.Cin % BK == 0 && !getenv("Y5_NO_UT"))
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 3, S, BK, false, true>), grid, block, Cfg::SMEM, s, a);
+    else if (ksize == 3)
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 3, S, BK, false>), grid, block, Cfg::SMEM, s, a);
     else if (direct)
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1, S, BK, true>), grid, block, Cfg::SMEM, s, a);
