@@ -82,6 +82,43 @@ __device__ __forceinline__ void wait_vm_and_barrier(int n) {
 #undef Y5_WAIT_CASE
 }
 
+// Per-channel epilogue parameters of a workgroup's BN channels, staged in LDS as [bias | scale | shift][BN] floats at
+// kernel start: read from global memory in the epilogue they would cost a dependent memory round trip per workgroup
+// just when nothing else is left to overlap it.  fetch -> (issue the prologue DMA) -> store.
+struct EpiParams {
+    float b, s, h;
+};
+__device__ __forceinline__ EpiParams epi_fetch(const ConvArgs& a, int n0, int t, int bn) {
+    EpiParams p = {0.f, 1.f, 0.f};
+    const int n = n0 + t;
+    if (t < bn && n < a.Cout) {
+        if (a.bias) p.b = a.bias[n];
+        if (a.scale) {
+            p.s = a.scale[n];
+            p.h = a.shift[n];
+        }
+    }
+    return p;
+}
+__device__ __forceinline__ void epi_store(float* prm, const EpiParams& p, int t, int bn) {
+    if (t < bn) {
+        prm[t] = p.b;
+        prm[bn + t] = p.s;
+        prm[2 * bn + t] = p.h;
+    }
+}
+// Post-ops on four consecutive channels nl..nl+3 (workgroup-local, nl % 4 == 0) of one pixel, parameters from LDS.
+__device__ __forceinline__ f16x4 post_op4_lds(f32x4 v, int nl, const float* prm, int bn, bool has_bias, bool has_scale, float slope) {
+    if (has_bias) v += *reinterpret_cast<const f32x4*>(prm + nl);
+    f16x4 h = __builtin_convertvector(v, f16x4);
+    if (has_scale)
+        h = __builtin_convertvector(__builtin_convertvector(h, f32x4) * *reinterpret_cast<const f32x4*>(prm + bn + nl) +
+                                        *reinterpret_cast<const f32x4*>(prm + 2 * bn + nl),
+                                    f16x4);
+    const f16x4 t = __builtin_convertvector(__builtin_convertvector(h, f32x4) * slope, f16x4);
+    return __builtin_elementwise_max(h, t);
+}
+
 // Post-ops on four consecutive channels n..n+3 of one pixel (n % 4 == 0, n + 3 < Cout).
 __device__ __forceinline__ f16x4 post_op4(f32x4 v, int n, const ConvArgs& a) {
     if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);

@@ -16,6 +16,13 @@ namespace {
 
 #include "conv_common.h"
 
+#ifdef Y5_STAMPS
+__device__ unsigned long long y5_stamph_buf[8 * 65536];
+#define Y5_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#else
+#define Y5_T(v)
+#endif
+
 constexpr int TH = 8, TW = 16;            // output pixels per workgroup
 constexpr int HBM_ = TH * TW;             // 128 rows of the GEMM tile
 constexpr int CK = 32;                    // input channels per chunk
@@ -49,6 +56,9 @@ __global__ __launch_bounds__(256) void conv_halo3x3_kernel(const ConvArgs a) {
     const int tile = xcd_remap(blockIdx.x, a.tiles_total);
     const int mtile = tile / a.tiles_n, nt = tile - mtile * a.tiles_n;
     const int n0 = nt * BN;
+    constexpr int PRM0 = (RING0 + SB * ST_BYTES > HBM_ * EP) ? RING0 + SB * ST_BYTES : HBM_ * EP;
+    float* prm = reinterpret_cast<float*>(smem + PRM0);
+    const EpiParams epi = epi_fetch(a, n0, t, BN);
     const unsigned b = fdiv((unsigned)mtile, a.div_tpi);
     const unsigned rem = (unsigned)mtile - b * (unsigned)(a.tiles_x * a.tiles_y);
     const unsigned tyi = fdiv(rem, a.div_tx), txi = rem - tyi * (unsigned)a.tiles_x;
@@ -116,10 +126,16 @@ __global__ __launch_bounds__(256) void conv_halo3x3_kernel(const ConvArgs a) {
     for (int i = 0; i < RM; ++i) arec[i] = (wm * (WTM / 16) + 2 * i + dy) * PITCH + tx;
     const int swb = (lr >> 2) & 3;
 
+#ifdef Y5_STAMPS
+    unsigned long long st[3] = {0, 0, 0};
+    const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+#endif
     const int total = a.nchunks * 3;
     issue_halo(0, 0);
     issue_b(0, 0, 0);
     if (total > 1) issue_b(0, 1, 1);
+    epi_store(prm, epi, t, BN);  // published by the barriers of the step loop
+    const bool has_bias = a.bias != nullptr, has_scale = a.scale != nullptr;
     int it = 0;
     for (int ci = 0; ci < a.nchunks; ++ci) {
         const bool more = ci + 1 < a.nchunks;
@@ -127,13 +143,16 @@ __global__ __launch_bounds__(256) void conv_halo3x3_kernel(const ConvArgs a) {
             // younger than what this step reads: the next step's weights and, in rows 1 and 2, the next chunk's halo
             int allowed = (it + 1 < total) ? lpsb : 0;
             if (more && r >= 1) allowed += HALO_DMA;
+            Y5_T(s0);
             wait_vm_and_barrier(allowed);
+            Y5_T(s1);
             if (it + 2 < total) {
                 const int nx = it + 2;
                 const int nci = nx >= (ci + 1) * 3 ? ci + 1 : ci;
                 issue_b(nci, nx - nci * 3, nx % SB);
             }
             if (r == 0 && more) issue_halo(ci + 1, (ci + 1) & 1);
+            Y5_T(s2);
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const unsigned char* Hb = smem + (ci & 1) * HALO_BYTES + (r * PITCH + q) * REC;
@@ -155,8 +174,15 @@ __global__ __launch_bounds__(256) void conv_halo3x3_kernel(const ConvArgs a) {
                             acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], xf[i], acc[j][i], 0, 0, 0);
                 }
             }
+#ifdef Y5_STAMPS
+            const unsigned long long s3 = __builtin_amdgcn_s_memtime();
+            st[0] += s1 - s0; st[1] += s2 - s1; st[2] += s3 - s2;
+#endif
         }
     }
+#ifdef Y5_STAMPS
+    const unsigned long long st_loop_end = __builtin_amdgcn_s_memtime();
+#endif
     wait_vm_and_barrier(0);
 
     // ---- epilogue (same staging as the im2col kernel; tile row p is pixel (p/16, p%16) of the block)
@@ -171,7 +197,7 @@ __global__ __launch_bounds__(256) void conv_halo3x3_kernel(const ConvArgs a) {
                 for (int i = 0; i < RM; ++i) {
                     const f32x4 v = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
                     const int ml = wm * WTM + i * 32 + lr;
-                    *reinterpret_cast<f16x4*>(smem + ml * EP + nl * 2) = post_op4(v, n, a);
+                    *reinterpret_cast<f16x4*>(smem + ml * EP + nl * 2) = post_op4_lds(v, nl, prm, BN, has_bias, has_scale, a.slope);
                 }
             }
         }
@@ -194,6 +220,13 @@ __global__ __launch_bounds__(256) void conv_halo3x3_kernel(const ConvArgs a) {
             }
         }
     }
+#ifdef Y5_STAMPS
+    if (lane == 0 && blockIdx.x * 4 + wave < 65536) {
+        unsigned long long* o = y5_stamph_buf + (size_t)(blockIdx.x * 4 + wave) * 8;
+        o[0] = st[0]; o[1] = st[1]; o[2] = st[2]; o[3] = st_loop_end - st_begin;
+        o[4] = __builtin_amdgcn_s_memtime() - st_loop_end; o[5] = st_begin; o[6] = total;
+    }
+#endif
 }
 
 template <int BN, int WM, int WN>
@@ -203,7 +236,7 @@ int launch_halo(ConvArgs a, hipStream_t s) {
     if (total <= 0 || total > 0x7fffffffLL) return y5_fail(Y5_EINVAL, "conv: tile count %lld out of range", total);
     a.tiles_total = (int)total;
     constexpr int ring = 2 * HALO_BYTES + 3 * 3 * BN * REC, ep = HBM_ * (BN * 2 + 16);
-    constexpr int smem = ring > ep ? ring : ep;
+    constexpr int smem = (ring > ep ? ring : ep) + 3 * BN * 4;
     static bool attr_set = false;  // per process
     if (!attr_set) {
         Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo3x3_kernel<BN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -215,6 +248,12 @@ int launch_halo(ConvArgs a, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef Y5_STAMPS
+extern "C" int y5_debug_stampsh(unsigned long long* dst, int n_waves) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(y5_stamph_buf), (size_t)n_waves * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
+#endif
 
 // Returns 1 when the halo-tile kernel handled the convolution, 0 when the caller should use the im2col kernel.
 int y5_try_conv_halo(const y5_conv_desc& d, hipStream_t s, int force_bn, int* rc) {

@@ -36,7 +36,8 @@ struct IgemmCfg {
     static constexpr int NT = 64 * WM * WN;
     static constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
     static constexpr int EP = BN * 2 + 16;  // epilogue row pitch in bytes
-    static constexpr int SMEM = (S * STAGE_BYTES > BM * EP) ? S * STAGE_BYTES : BM * EP;
+    static constexpr int PRM0 = (S * STAGE_BYTES > BM * EP) ? S * STAGE_BYTES : BM * EP;  // epilogue parameters behind ring / tile
+    static constexpr int SMEM = PRM0 + 3 * BN * 4;
 };
 
 // UT ("uniform tap", KS = 3 with Cin a multiple of BK): every chunk of a K-step belongs to the same tap, so the tap's
@@ -74,6 +75,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
     const int mt = tile / a.tiles_n, nt = tile - mt * a.tiles_n;
     const int m0 = mt * BM;  // M < 2^31 is checked by the launcher
     const int n0 = nt * BN;
+    float* prm = reinterpret_cast<float*>(smem + IgemmCfg<BM, BN, WM, WN, S, BK>::PRM0);
+    const EpiParams epi = epi_fetch(a, n0, t, BN);
 
     // ---- per-thread gather state.  Thread t fills LDS slot (row = t/CPRW [+RPI*i], 16-byte slot t%CPRW) of
     // every stage; with the XOR swizzle that slot holds K-chunk kc of the row.
@@ -220,6 +223,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
 #pragma unroll
     for (int s = 0; s < S - 1; ++s)
         if (s < nk) issue(s);
+    epi_store(prm, epi, t, BN);  // published by the barriers of the K loop
+    const bool has_bias = a.bias != nullptr, has_scale = a.scale != nullptr;
 #ifdef Y5_STAMPS
     unsigned long long st_wait = 0, st_issue = 0, st_mma = 0;
     const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
                 for (int i = 0; i < RM; ++i) {
                     const f32x4 v = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
                     const int ml = wm * WTM + i * 32 + lr;
-                    *reinterpret_cast<f16x4*>(smem + ml * EP + nl * 2) = post_op4(v, n, a);
+                    *reinterpret_cast<f16x4*>(smem + ml * EP + nl * 2) = post_op4_lds(v, nl, prm, BN, has_bias, has_scale, a.slope);
                 }
             }
         }
