@@ -112,7 +112,7 @@ __device__ __forceinline__ void finish_rows(const f32x16 (&acc)[BN / 32], const 
     }
 }
 
-template <int CIN, int BN, int STRIDE, int MODE>
+template <int CIN, int BN, int STRIDE, int MODE, int DEPTH>
 __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const WsArgs a) {
     typedef Patch<CIN, STRIDE> P;
     constexpr int RN = BN / 32;
@@ -177,7 +177,6 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const WsArgs a) {
     const int tiles_per_img = a.tiles_x * a.tiles_y;
     // Input patches are fetched DEPTH tiles ahead into registers (set k holds a tile whose sequence number is k modulo
     // DEPTH): with one workgroup per CU a single patch in flight leaves the tile period equal to the memory latency.
-    constexpr int DEPTH = 1;
     uint4 pre[DEPTH][P::NSLOT];
     auto fetch = [&](int tile, uint4 (&pre)[P::NSLOT]) {
         const int b = tile / tiles_per_img, rem = tile - b * tiles_per_img;
@@ -290,7 +289,9 @@ int launch_ws3m(WsArgs a, hipStream_t s) {
     typedef Patch<CIN, STRIDE> P;
     constexpr size_t lds = (size_t)BN * (9 * CIN * 2 + 16) + P::BYTES + 4 * 32 * (BN * 2 + 16);
     static_assert(lds <= 160 * 1024, "configuration does not fit in LDS");
-    auto kern = conv3x3_ws_kernel<CIN, BN, STRIDE, MODE>;
+    // a configuration that leaves room for only one workgroup per CU has registers to spare: fetch two tiles ahead
+    constexpr int DEPTH = lds > 80 * 1024 ? 2 : 1;
+    auto kern = conv3x3_ws_kernel<CIN, BN, STRIDE, MODE, DEPTH>;
     static bool attr_set = false;
     if (!attr_set) {
         Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
