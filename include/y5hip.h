@@ -233,6 +233,14 @@ int y5_plan_add_upsample2x(y5_plan* p, const void* x, int x_ld, void* y, int y_l
 int y5_plan_add_copy_channels(y5_plan* p, const void* x, int x_ld, void* y, int y_ld, int64_t pixels, int c);
 int y5_plan_add_decode(y5_plan* p, const y5_decode_desc* d);
 int y5_plan_add_decode_multi(y5_plan* p, const y5_decode_desc* levels, int n_levels);
+/* Mark the op recorded last.  Y5_PLAN_SIDE: y5_plan_run launches it on a second stream owned by the plan, ordered
+ * after everything issued before it on the caller's stream -- for an op whose result is needed only much later (the
+ * Detect convs of the finer pyramid levels, which can run beside the rest of the head).  Y5_PLAN_JOIN: the caller's
+ * stream waits for the side stream before this op.  The end of the plan always joins.  One y5_plan_run at a time per
+ * plan.  y5_plan_profile ignores the marks (everything in order on one stream). */
+#define Y5_PLAN_SIDE 1
+#define Y5_PLAN_JOIN 2
+int y5_plan_mark_last(y5_plan* p, int flags);
 int y5_plan_num_ops(const y5_plan* p);
 /* Replay all ops on `stream`. ext (host array of n_ext device pointers) supplies the external slots. */
 int y5_plan_run(y5_plan* p, void* const* ext, int n_ext, y5_stream_t stream);

@@ -56,6 +56,26 @@ def test_forward_against_oracle(dev, cfg, fuse, shape):
     agree(z, zt, 0.90)
 
 
+def test_side_stream_plan_gives_the_same_tensors(dev, monkeypatch):
+    """Y5_SIDE_STREAM=1 records the early Detect convolutions on the plan's second stream (y5_plan_mark_last): same
+    kernels, same order per stream, so every output must be bit-identical to the single-stream plan."""
+    model = util.build_model('yolov5s')
+    util.randomize_bn(model, 3)
+    model = model.eval().half().to(dev)
+    x = torch.rand(3, 3, 96, 128, generator=torch.Generator().manual_seed(9)).half().to(dev)
+    z0, xs0 = model(x)
+    monkeypatch.setenv('Y5_SIDE_STREAM', '1')
+    plan = engine.Plan(model, x)
+    try:
+        assert any('side stream' in label for label in plan.labels)
+        for _ in range(3):
+            z1, xs1 = plan.run(x)
+        torch.cuda.synchronize()
+    finally:
+        plan.close()
+    assert torch.equal(z0, z1) and all(torch.equal(a, b) for a, b in zip(xs0, xs1))
+
+
 def test_detections_match_oracle_on_engine_output(dev):
     """forward -> non_max_suppression on the GPU; the NMS stage must reproduce the oracle exactly on the very
     predictions the engine produced (kept boxes are bit-identical given identical scores)."""

@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, 'liby5hip.so')
 
 Y5_MAX_ANCHORS = 8
 Y5_MAX_LEVELS = 4
+PLAN_SIDE, PLAN_JOIN = 1, 2
 ACT_NONE, ACT_LEAKY = 0, 1
 OK, EINVAL, EHIP, ENOMEM, EWORKSPACE = 0, -1, -2, -3, -4  # y5_status in include/y5hip.h
 OP_NAMES = {8: 'focus_conv', 9: 'decode', 1: 'conv', 2: 'pack', 3: 'maxpool', 4: 'upsample', 5: 'copy', 6: 'decode', 7: 'maxpool'}
@@ -74,6 +75,7 @@ SIGNATURES = {
     'y5_plan_add_copy_channels': (_i, [_p, _p, _i, _p, _i, C.c_int64, _i]),
     'y5_plan_add_decode': (_i, [_p, C.POINTER(DecodeDesc)]),
     'y5_plan_add_decode_multi': (_i, [_p, C.POINTER(DecodeDesc), C.c_int]),
+    'y5_plan_mark_last': (_i, [_p, C.c_int]),
     'y5_plan_num_ops': (_i, [_p]),
     'y5_plan_run': (_i, [_p, C.POINTER(_p), _i, _s]),
     'y5_plan_profile': (_i, [_p, C.POINTER(_p), _i, _s, C.POINTER(C.c_float), _i]),

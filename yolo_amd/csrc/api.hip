@@ -106,6 +106,7 @@ struct Op {
     long long pixels = 0;
     std::vector<PtrFix> fixes;
     double flops = 0.0, bytes = 0.0;
+    int flags = 0;  // Y5_PLAN_SIDE / Y5_PLAN_JOIN
 };
 
 }  // namespace
@@ -113,6 +114,15 @@ struct Op {
 struct y5_plan {
     std::vector<Op> ops;
     SlotRange slots[16];
+    // side stream for ops marked Y5_PLAN_SIDE and the events that order it against the caller's stream; created on
+    // first use on the device that is current then
+    hipStream_t side = nullptr;
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    ~y5_plan() {
+        if (fork_ev) (void)hipEventDestroy(fork_ev);
+        if (join_ev) (void)hipEventDestroy(join_ev);
+        if (side) (void)hipStreamDestroy(side);
+    }
 };
 
 namespace {
@@ -340,6 +350,13 @@ extern "C" int y5_plan_add_decode_multi(y5_plan* p, const y5_decode_desc* levels
     });
 }
 
+extern "C" int y5_plan_mark_last(y5_plan* p, int flags) {
+    Y5_REQUIRE(p && !p->ops.empty(), "plan_mark_last: no op recorded yet");
+    Y5_REQUIRE((flags & ~(Y5_PLAN_SIDE | Y5_PLAN_JOIN)) == 0, "plan_mark_last: unknown flags 0x%x", flags);
+    p->ops.back().flags |= flags;
+    return Y5_OK;
+}
+
 extern "C" int y5_plan_num_ops(const y5_plan* p) { return p ? (int)p->ops.size() : 0; }
 
 extern "C" int y5_plan_op_info(const y5_plan* p, int i, int* kind, double* flops, double* bytes) {
@@ -350,19 +367,54 @@ extern "C" int y5_plan_op_info(const y5_plan* p, int i, int* kind, double* flops
     return Y5_OK;
 }
 
+namespace {
+
+int ensure_side_stream(y5_plan* p) {
+    if (p->side) return Y5_OK;
+    Y5_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+    Y5_HIP(hipEventCreateWithFlags(&p->fork_ev, hipEventDisableTiming));
+    Y5_HIP(hipEventCreateWithFlags(&p->join_ev, hipEventDisableTiming));
+    return Y5_OK;
+}
+
+// main waits for everything issued to the side stream so far
+int join_side(y5_plan* p, hipStream_t main) {
+    Y5_HIP(hipEventRecord(p->join_ev, p->side));
+    Y5_HIP(hipStreamWaitEvent(main, p->join_ev, 0));
+    return Y5_OK;
+}
+
+}  // namespace
+
 extern "C" int y5_plan_run(y5_plan* p, void* const* ext, int n_ext, y5_stream_t stream) {
     Y5_REQUIRE(p, "plan_run: null plan");
     hipStream_t s = static_cast<hipStream_t>(stream);
     return guarded([&]() {
         Op op;
+        bool side_busy = false;
         for (size_t k = 0; k < p->ops.size(); ++k) {
             const Op* cur = &p->ops[k];
             if (!cur->fixes.empty()) {
                 if (int rc = resolve(p, k, ext, n_ext, op)) return rc;
                 cur = &op;
             }
-            if (int rc = run_op(*cur, s)) return rc;
+            if ((cur->flags & Y5_PLAN_JOIN) && side_busy) {
+                if (int rc = join_side(p, s)) return rc;
+                side_busy = false;
+            }
+            if (cur->flags & Y5_PLAN_SIDE) {
+                if (int rc = ensure_side_stream(p)) return rc;
+                // the side stream starts this op once everything issued to the caller's stream so far is done
+                Y5_HIP(hipEventRecord(p->fork_ev, s));
+                Y5_HIP(hipStreamWaitEvent(p->side, p->fork_ev, 0));
+                if (int rc = run_op(*cur, p->side)) return rc;
+                side_busy = true;
+            } else if (int rc = run_op(*cur, s)) {
+                return rc;
+            }
         }
+        if (side_busy)
+            if (int rc = join_side(p, s)) return rc;  // the caller's stream stands for the whole plan
         return (int)Y5_OK;
     });
 }
