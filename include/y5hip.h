@@ -95,6 +95,13 @@ int y5_conv_num_variants(void);
  * channel c at row parity dy, column parity dx; cout <= 96; res must be NULL; variant is ignored. */
 int y5_focus_conv_f16(const y5_conv_desc* d, y5_stream_t stream);
 
+/* Image pre-processing on the device, the step before the path: img.half() followed by img /= 255.0
+ * (test.py:152-154, detect.py:57-59): y[i] = fp16(float(x[i]) / 255.0f) for n uint8 values (any layout). */
+int y5_normalize_u8_f16(const void* x_u8, void* y_f16, int64_t n, y5_stream_t stream);
+/* y5_focus_conv_f16 with that pre-processing folded in: x is the uint8 NCHW image as the data loader delivers it
+ * (utils/datasets.py:140-141 after .to(device)); results are bit-identical to normalising first. */
+int y5_focus_conv_u8(const y5_conv_desc* d, y5_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Input packing: NCHW fp16 image batch -> NHWC fp16, optionally with the Focus space-to-depth
  * gather. Replaces: Focus.forward's four strided slices + cat  models/common.py:85-86
@@ -222,6 +229,8 @@ void y5_plan_destroy(y5_plan* p);
 int y5_plan_bind_slot(y5_plan* p, int slot, const void* base, size_t bytes);
 int y5_plan_add_conv(y5_plan* p, const y5_conv_desc* d);
 int y5_plan_add_focus_conv(y5_plan* p, const y5_conv_desc* d);
+int y5_plan_add_focus_conv_u8(y5_plan* p, const y5_conv_desc* d);
+int y5_plan_add_normalize_u8(y5_plan* p, const void* x_u8, void* y_f16, int64_t n);
 int y5_plan_add_pack_image(y5_plan* p, const void* x_nchw, void* y_nhwc, int batch, int c, int h, int w, int focus,
                            int y_ld);
 int y5_plan_add_maxpool(y5_plan* p, const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c,
@@ -257,6 +266,8 @@ int y5_plan_profile(y5_plan* p, void* const* ext, int n_ext, y5_stream_t stream,
 #define Y5_OP_MAXPOOL_CASCADE 7
 #define Y5_OP_FOCUS_CONV 8
 #define Y5_OP_DECODE_MULTI 9
+#define Y5_OP_FOCUS_CONV_U8 10
+#define Y5_OP_NORMALIZE_U8 11
 int y5_plan_op_info(const y5_plan* p, int i, int* kind, double* flops, double* bytes);
 
 #ifdef __cplusplus

@@ -221,6 +221,34 @@ def test_focus_conv_from_the_nchw_image(dev, shape):
         close(y[..., :Co].permute(0, 3, 1, 2), ref)
 
 
+@pytest.mark.parametrize('shape', [(2, 64, 96, 32), (3, 42, 74, 48), (1, 160, 128, 80)], ids=lambda s: 'x'.join(map(str, s)))
+def test_focus_conv_u8_equals_normalise_then_focus_conv(dev, shape):
+    """y5_focus_conv_u8 folds img.half() / 255.0 into the stem kernel: bit-identical to normalising first."""
+    from yolo_amd import preprocess
+    lib = _lib.lib()
+    B, H, W, Co = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    img8 = torch.randint(0, 256, (B, 3, H, W), generator=g, dtype=torch.int32).to(torch.uint8).to(dev)
+    img16 = preprocess.normalize(img8)
+    wp = torch.zeros(128, 192, dtype=torch.float16, device=dev)
+    wp[:Co, :144] = (torch.randn(Co, 144, generator=g) / 10).half().to(dev)
+    wp.view(128, 12, 16)[:, :, 12:] = 0
+    bias = torch.randn(Co, generator=g).to(dev)
+    outs = []
+    for img, fn in ((img16, lib.y5_focus_conv_f16), (img8, lib.y5_focus_conv_u8)):
+        y = torch.zeros(B, H // 2, W // 2, Co, dtype=torch.float16, device=dev)
+        d = _lib.ConvDesc()
+        d.x, d.w, d.y, d.bias = img.data_ptr(), wp.data_ptr(), y.data_ptr(), bias.data_ptr()
+        d.batch, d.h, d.w_in, d.cin = B, H, W, 3
+        d.ho, d.wo, d.cout, d.y_ld = H // 2, W // 2, Co, Co
+        d.ksize, d.stride, d.pad, d.kpad, d.w_rows = 3, 1, 1, 192, 128
+        d.act, d.slope = _lib.ACT_LEAKY, 0.1
+        _lib.check(fn(C.byref(d), _lib.current_stream()))
+        outs.append(y)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and float(outs[0].abs().max()) > 0
+
+
 def test_conv_into_channel_slice_leaves_neighbours_alone(dev):
     """Concat in place: writing a 32-channel result into channels [64, 96) of a 128-channel buffer."""
     lib = _lib.lib()

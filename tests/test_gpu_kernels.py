@@ -151,6 +151,20 @@ def test_decode_full_size_level_against_oracle(dev):
     assert torch.equal(xo.cpu(), xr[0]) and torch.equal(zo.cpu().view(torch.int16), zr.view(torch.int16))
 
 
+def test_normalize_u8_equals_half_then_divide(dev):
+    """y5_normalize_u8_f16 against torch's CPU `img.half() / 255.0` (test.py:152-154): every byte value, and a tensor
+    whose size is not a multiple of the 16-byte vector."""
+    from yolo_amd import preprocess
+    allv = torch.arange(256, dtype=torch.int32).to(torch.uint8)
+    g = torch.Generator().manual_seed(2)
+    odd = torch.randint(0, 256, (3, 3, 37, 41), generator=g, dtype=torch.int32).to(torch.uint8)
+    for t in (allv, odd):
+        got = preprocess.normalize(t.to(dev))
+        ref = t.half() / 255.0
+        assert got.dtype is torch.float16 and got.shape == t.shape
+        assert torch.equal(got.cpu().view(torch.int16), ref.view(torch.int16))
+
+
 def test_sigmoid_of_every_fp16_value(dev):
     """The decode kernel's 4-instruction sigmoid against the libm/IEEE-division form and against torch's CPU half
     sigmoid (the op the reference applies, models/yolo.py:41) on all 65536 bit patterns."""

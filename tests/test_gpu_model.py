@@ -76,6 +76,24 @@ def test_side_stream_plan_gives_the_same_tensors(dev, monkeypatch):
     assert torch.equal(z0, z1) and all(torch.equal(a, b) for a, b in zip(xs0, xs1))
 
 
+def test_uint8_batch_runs_on_the_engine_like_its_normalised_copy(dev):
+    """A half model accepts the data loader's uint8 batch (the engine applies test.py:152-154 in its first kernel):
+    same tensors as model(img.half() / 255.0), on the engine, and the torch walk offers the same convenience."""
+    from yolo_amd import preprocess
+    model = util.build_model('yolov5s')
+    util.randomize_bn(model, 4)
+    model = model.eval().half().to(dev)
+    img8 = torch.randint(0, 256, (2, 3, 96, 64), generator=torch.Generator().manual_seed(1), dtype=torch.int32).to(torch.uint8).to(dev)
+    z0, xs0 = model(preprocess.normalize(img8))
+    n0 = calls(model)
+    z1, xs1 = model(img8)
+    assert calls(model) == n0 + 1, 'the uint8 forward must run on the HIP engine'
+    assert torch.equal(z0, z1) and all(torch.equal(a, b) for a, b in zip(xs0, xs1))
+    with engine.disabled():
+        zt, _ = model(img8)
+    agree(z1, zt, 0.90)
+
+
 def test_detections_match_oracle_on_engine_output(dev):
     """forward -> non_max_suppression on the GPU; the NMS stage must reproduce the oracle exactly on the very
     predictions the engine produced (kept boxes are bit-identical given identical scores)."""

@@ -48,6 +48,13 @@ extern "C" int y5_focus_conv_f16(const y5_conv_desc* d, y5_stream_t stream) {
 extern "C" int y5_sigmoid_f16(const void* x, void* y, int64_t n, int libm, y5_stream_t stream) {
     return y5_launch_sigmoid(x, y, n, libm, static_cast<hipStream_t>(stream));
 }
+extern "C" int y5_focus_conv_u8(const y5_conv_desc* d, y5_stream_t stream) {
+    Y5_REQUIRE(d, "focus_conv_u8: null descriptor");
+    return y5_launch_focus_conv(*d, static_cast<hipStream_t>(stream), true);
+}
+extern "C" int y5_normalize_u8_f16(const void* x, void* y, int64_t n, y5_stream_t stream) {
+    return y5_launch_normalize_u8(x, y, n, static_cast<hipStream_t>(stream));
+}
 extern "C" int y5_conv_num_variants(void) { return y5_conv_variant_count(); }
 extern "C" int y5_pack_image_f16(const void* x, void* y, int batch, int c, int h, int w, int focus, int y_ld,
                                  y5_stream_t stream) {
@@ -145,6 +152,7 @@ bool set_ptr(Op& op, int field, const void* v) {
     switch (op.kind) {
         case Y5_OP_CONV:
         case Y5_OP_FOCUS_CONV:
+        case Y5_OP_FOCUS_CONV_U8:
             if (field == 0) op.conv.x = v;
             else if (field == 1) op.conv.y = nv;
             else if (field == 2) op.conv.res = v;
@@ -176,6 +184,8 @@ int run_op(const Op& op, hipStream_t s) {
     switch (op.kind) {
         case Y5_OP_CONV: return y5_launch_conv(op.conv, s);
         case Y5_OP_FOCUS_CONV: return y5_launch_focus_conv(op.conv, s);
+        case Y5_OP_FOCUS_CONV_U8: return y5_launch_focus_conv(op.conv, s, true);
+        case Y5_OP_NORMALIZE_U8: return y5_launch_normalize_u8(op.px, op.py, op.pixels, s);
         case Y5_OP_PACK: return y5_launch_pack_image(op.px, op.py, op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], s);
         case Y5_OP_MAXPOOL: return y5_launch_maxpool(op.px, op.i[0], op.py, op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6], s);
         case Y5_OP_MAXPOOL_CASCADE:
@@ -250,17 +260,22 @@ extern "C" int y5_plan_add_conv(y5_plan* p, const y5_conv_desc* d) {
     });
 }
 
-extern "C" int y5_plan_add_focus_conv(y5_plan* p, const y5_conv_desc* d) {
+static int add_focus_conv(y5_plan* p, const y5_conv_desc* d, int kind);
+extern "C" int y5_plan_add_focus_conv(y5_plan* p, const y5_conv_desc* d) { return add_focus_conv(p, d, Y5_OP_FOCUS_CONV); }
+extern "C" int y5_plan_add_focus_conv_u8(y5_plan* p, const y5_conv_desc* d) { return add_focus_conv(p, d, Y5_OP_FOCUS_CONV_U8); }
+
+static int add_focus_conv(y5_plan* p, const y5_conv_desc* d, int kind) {
     Y5_REQUIRE(p && d, "plan_add_focus_conv: null argument");
     return guarded([&]() {
         Op op;
-        op.kind = Y5_OP_FOCUS_CONV;
+        op.kind = kind;
         op.conv = *d;
         note_ptr(p, op, 0, d->x);
         note_ptr(p, op, 1, d->y);
         const double m = (double)d->batch * d->ho * d->wo;
         op.flops = 2.0 * m * d->cout * 9 * 4 * d->cin;
-        op.bytes = 2.0 * ((double)d->batch * d->h * d->w_in * d->cin + m * d->cout + (double)d->cout * 9 * 4 * d->cin);
+        op.bytes = (kind == Y5_OP_FOCUS_CONV_U8 ? 1.0 : 2.0) * d->batch * d->h * d->w_in * d->cin +
+                   2.0 * (m * d->cout + (double)d->cout * 9 * 4 * d->cin);
         p->ops.push_back(op);
         return Y5_OK;
     });
@@ -287,6 +302,11 @@ extern "C" int y5_plan_add_pack_image(y5_plan* p, const void* x, void* y, int ba
     const int iv[6] = {batch, c, h, w, focus, y_ld};
     const double px = (double)batch * h * w;
     return add_pointwise(p, Y5_OP_PACK, x, y, iv, 6, 0, 2.0 * px * c + 2.0 * (focus ? px / 4 : px) * y_ld);
+}
+
+extern "C" int y5_plan_add_normalize_u8(y5_plan* p, const void* x, void* y, int64_t n) {
+    Y5_REQUIRE(p, "plan_add_normalize_u8: null plan");
+    return add_pointwise(p, Y5_OP_NORMALIZE_U8, x, y, nullptr, 0, n, 3.0 * (double)n);
 }
 
 extern "C" int y5_plan_add_maxpool(y5_plan* p, const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c, int k) {

@@ -14,7 +14,7 @@
 namespace {
 
 struct FocusArgs {
-    const f16* img;   // [B][3][H][W]
+    const void* img;  // [B][3][H][W], fp16 or (U8 kernels) uint8 to be divided by 255
     const f16* w;     // packed rows, k = (r*3 + q)*16 + (dy + 2*dx)*3 + c
     const float *bias, *scale, *shift;
     f16* y;
@@ -67,7 +67,9 @@ __device__ __forceinline__ void finish_tile(const f32x16 (&acc)[2][RN], const Fo
     }
 }
 
-template <int RN>
+// U8: the image is uint8 and the kernel applies the reference's pre-processing img.half() / 255.0 (test.py:152-154) on
+// the way in, through a 256-entry table of fp16(float(v) / 255.0f) -- the input then costs a quarter of the fp16 bytes.
+template <int RN, bool U8>
 __global__ __launch_bounds__(256) void focus_conv_kernel(const FocusArgs a) {
     constexpr int CN = RN * 32;                    // channels held by the workgroup
     constexpr int EROW = CN * 2 + 16;              // bytes per pixel in a wave's output scratch
@@ -76,6 +78,7 @@ __global__ __launch_bounds__(256) void focus_conv_kernel(const FocusArgs a) {
     uint32_t* patch = reinterpret_cast<uint32_t*>(smem + CN * kWPitch * 2);        // 2 x [3][kPatchRows][kPatchDw] (+ slack)
     unsigned char* scr = smem + CN * kWPitch * 2 + 2 * kPatchBuf * 4;              // [4 waves][32][EROW]
     float* prm = reinterpret_cast<float*>(scr + 4 * 32 * EROW);                    // [3][CN]
+    f16* norm = reinterpret_cast<f16*>(prm + 3 * CN);                               // [256], U8 only
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int lr = lane & 31, lh = lane >> 5;
@@ -88,6 +91,7 @@ __global__ __launch_bounds__(256) void focus_conv_kernel(const FocusArgs a) {
         if (q6 < 6) v = a.w[(size_t)n * a.w_ld + ((r6 >> 1) * 3 + (q6 >> 1)) * 16 + ((r6 & 1) + 2 * (q6 & 1)) * 3 + c];
         wl[n * kWPitch + rem] = v;
     }
+    if (U8) norm[t] = (f16)((float)t / 255.0f);  // 256 threads, 256 entries; published by the first barrier below
     if (t < CN) {
         const bool in = t < a.Cout;
         prm[t] = a.bias && in ? a.bias[t] : 0.f;
@@ -105,40 +109,51 @@ __global__ __launch_bounds__(256) void focus_conv_kernel(const FocusArgs a) {
     // registers one tile ahead) are stored to the other, and the fetch after next is issued before the epilogue.
     const int r7 = t / kPatchDw, dwc = t - r7 * kPatchDw;
     const bool stager = t < kSlabRows * kPatchDw;
-    const unsigned voff = (unsigned)(r7 * a.W + 2 * dwc) * 2u;  // bytes from a slab's first element
+    const unsigned voff = (unsigned)(r7 * a.W + 2 * dwc) * (U8 ? 1u : 2u);  // bytes from a slab's first element
     uint32_t pre[kSlabs];
     auto fetch = [&](int tile) {
         const int b = tile / tiles_per_img, rem = tile - b * tiles_per_img;
         const int iy0 = 2 * ((rem / a.tiles_x) * 8) - 2, ix0 = 2 * ((rem % a.tiles_x) * 32) - 2;
+        constexpr int ESZ = U8 ? 1 : 2;  // bytes per image element
         const unsigned char* origin =
-            reinterpret_cast<const unsigned char*>(a.img + (size_t)b * 3 * a.H * a.W + (ptrdiff_t)iy0 * a.W + ix0);
+            static_cast<const unsigned char*>(a.img) + ((ptrdiff_t)b * 3 * a.H * a.W + (ptrdiff_t)iy0 * a.W + ix0) * ESZ;
         const bool interior = iy0 >= 0 && iy0 + kPatchRows <= a.H && ix0 >= 0 && ix0 + 2 * kPatchDw <= a.W;
         if (!stager) return;
         if (interior) {
 #pragma unroll
             for (int i = 0; i < kSlabs; ++i) {
-                const unsigned char* slab = origin + ((size_t)(i / 3) * a.H + kSlabRows * (i % 3)) * a.W * 2;  // wave-uniform
-                pre[i] = *reinterpret_cast<const uint32_t*>(slab + voff);
+                const unsigned char* slab = origin + ((size_t)(i / 3) * a.H + kSlabRows * (i % 3)) * a.W * ESZ;  // wave-uniform
+                pre[i] = U8 ? *reinterpret_cast<const unsigned short*>(slab + voff) : *reinterpret_cast<const uint32_t*>(slab + voff);
             }
         } else {
             const int ix = ix0 + 2 * dwc;
             const bool xok = ix >= 0 && ix < a.W;
 #pragma unroll
             for (int i = 0; i < kSlabs; ++i) {
-                const unsigned char* slab = origin + ((size_t)(i / 3) * a.H + kSlabRows * (i % 3)) * a.W * 2;
+                const unsigned char* slab = origin + ((size_t)(i / 3) * a.H + kSlabRows * (i % 3)) * a.W * ESZ;
                 const int iy = iy0 + kSlabRows * (i % 3) + r7;
                 const bool ok = xok && iy >= 0 && iy < a.H;
-                const uint32_t v = *reinterpret_cast<const uint32_t*>(ok ? slab + voff : reinterpret_cast<const unsigned char*>(a.img));
-                pre[i] = ok ? v : 0u;
+                const unsigned char* src = ok ? slab + voff : static_cast<const unsigned char*>(a.img);
+                const uint32_t v = U8 ? *reinterpret_cast<const unsigned short*>(src) : *reinterpret_cast<const uint32_t*>(src);
+                pre[i] = ok ? v : 0u;  // padding: byte 0 maps to norm[0] = 0.0 as well
             }
         }
     };
     auto stage = [&](int buf) {
         if (!stager) return;
 #pragma unroll
-        for (int i = 0; i < kSlabs; ++i) patch[buf * kPatchBuf + i * kSlabRows * kPatchDw + t] = pre[i];
+        for (int i = 0; i < kSlabs; ++i) {
+            uint32_t v = pre[i];
+            if (U8) {  // two pixels, one byte each -> two normalised halfs (padding stays zero: norm[0] = 0)
+                const unsigned short lo = __builtin_bit_cast(unsigned short, norm[v & 255u]);
+                const unsigned short hi = __builtin_bit_cast(unsigned short, norm[(v >> 8) & 255u]);
+                v = (uint32_t)lo | (uint32_t)hi << 16;
+            }
+            patch[buf * kPatchBuf + i * kSlabRows * kPatchDw + t] = v;
+        }
     };
     const int first = blockIdx.x, stride = gridDim.x;
+    if (U8) __syncthreads();  // the normalisation table is read by the very first stage()
     if (first < a.ntiles) {
         fetch(first);
         stage(0);
@@ -195,25 +210,25 @@ __global__ __launch_bounds__(256) void focus_conv_kernel(const FocusArgs a) {
     }
 }
 
-template <int RN>
+template <int RN, bool U8>
 int launch_focus(const FocusArgs& a, hipStream_t s) {
     constexpr int CN = RN * 32;
-    constexpr size_t lds = (size_t)CN * kWPitch * 2 + 2 * kPatchBuf * 4 + 4 * 32 * (CN * 2 + 16) + 3 * CN * 4;
+    constexpr size_t lds = (size_t)CN * kWPitch * 2 + 2 * kPatchBuf * 4 + 4 * 32 * (CN * 2 + 16) + 3 * CN * 4 + 256 * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(focus_conv_kernel<RN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(focus_conv_kernel<RN, U8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const int per_cu = RN == 1 ? 4 : RN == 2 ? 3 : 2;
     const int grid = a.ntiles < 256 * per_cu ? a.ntiles : 256 * per_cu;
-    hipLaunchKernelGGL(focus_conv_kernel<RN>, dim3((unsigned)grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((focus_conv_kernel<RN, U8>), dim3((unsigned)grid), dim3(256), lds, s, a);
     Y5_LAUNCH_CHECK("focus_conv_kernel");
     return Y5_OK;
 }
 
 }  // namespace
 
-int y5_launch_focus_conv(const y5_conv_desc& d, hipStream_t s) {
+int y5_launch_focus_conv(const y5_conv_desc& d, hipStream_t s, bool u8) {
     Y5_REQUIRE(d.x && d.w && d.y, "focus_conv: null image, weight or output pointer");
     Y5_REQUIRE(d.cin == 3, "focus_conv: the image must have 3 channels (got %d)", d.cin);
     Y5_REQUIRE(d.ksize == 3 && d.stride == 1 && d.pad == 1, "focus_conv: only the 3x3 stride-1 pad-1 convolution is fused");
@@ -226,9 +241,9 @@ int y5_launch_focus_conv(const y5_conv_desc& d, hipStream_t s) {
     Y5_REQUIRE(!d.res, "focus_conv: no residual input");
     Y5_REQUIRE((d.scale == nullptr) == (d.shift == nullptr), "focus_conv: scale and shift come together");
     Y5_REQUIRE(d.act == Y5_ACT_NONE || (d.act == Y5_ACT_LEAKY && d.slope > 0.f && d.slope <= 1.f), "focus_conv: bad activation");
-    Y5_REQUIRE((reinterpret_cast<uintptr_t>(d.x) & 3u) == 0 && y5_aligned16(d.y) && y5_aligned16(d.w), "focus_conv: misaligned pointer");
+    Y5_REQUIRE((reinterpret_cast<uintptr_t>(d.x) & (u8 ? 1u : 3u)) == 0 && y5_aligned16(d.y) && y5_aligned16(d.w), "focus_conv: misaligned pointer");
     FocusArgs a{};
-    a.img = static_cast<const f16*>(d.x);
+    a.img = d.x;
     a.w = static_cast<const f16*>(d.w);
     a.bias = d.bias; a.scale = d.scale; a.shift = d.shift;
     a.y = static_cast<f16*>(d.y);
@@ -238,7 +253,12 @@ int y5_launch_focus_conv(const y5_conv_desc& d, hipStream_t s) {
     Y5_REQUIRE(nt < (1LL << 31), "focus_conv: too many tiles");
     a.ntiles = (int)nt;
     a.slope = d.act == Y5_ACT_LEAKY ? d.slope : 1.f;
-    if (d.cout <= 32) return launch_focus<1>(a, s);
-    if (d.cout <= 64) return launch_focus<2>(a, s);
-    return launch_focus<3>(a, s);
+    if (u8) {
+        if (d.cout <= 32) return launch_focus<1, true>(a, s);
+        if (d.cout <= 64) return launch_focus<2, true>(a, s);
+        return launch_focus<3, true>(a, s);
+    }
+    if (d.cout <= 32) return launch_focus<1, false>(a, s);
+    if (d.cout <= 64) return launch_focus<2, false>(a, s);
+    return launch_focus<3, false>(a, s);
 }

@@ -51,6 +51,26 @@ __global__ __launch_bounds__(kThreads) void pack_image_kernel(const f16* __restr
     }
 }
 
+// uint8 -> fp16 / 255: img.half() followed by img /= 255.0 (test.py:152-154).  The half division is evaluated in
+// fp32 and rounded once, which is what fp16(float(v) / 255.0f) with IEEE division gives; 16 values per thread.
+__global__ __launch_bounds__(kThreads) void normalize_u8_kernel(const uint8_t* __restrict__ x, f16* __restrict__ y, long long n) {
+    const long long nvec = n / 16;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += (long long)gridDim.x * kThreads) {
+        const uint4 v = reinterpret_cast<const uint4*>(x)[i];
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+        f16x8 lo, hi;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            lo[e] = (f16)((float)((w[e >> 2] >> (8 * (e & 3))) & 255u) / 255.0f);
+            hi[e] = (f16)((float)((w[2 + (e >> 2)] >> (8 * (e & 3))) & 255u) / 255.0f);
+        }
+        reinterpret_cast<f16x8*>(y)[2 * i] = lo;
+        reinterpret_cast<f16x8*>(y)[2 * i + 1] = hi;
+    }
+    for (long long i = nvec * 16 + (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads)
+        y[i] = (f16)((float)x[i] / 255.0f);
+}
+
 // One thread per (pixel, 8-channel vector).
 __global__ __launch_bounds__(kThreads) void maxpool_kernel(const f16* __restrict__ x, int x_ld, f16* __restrict__ y, int y_ld,
                                                            int batch, int H, int W, int C8, int k) {
@@ -167,6 +187,16 @@ int y5_launch_pack_image(const void* x, void* y, int batch, int c, int h, int w,
     hipLaunchKernelGGL(pack_image_kernel, dim3(grid_for(total)), dim3(kThreads), 0, s, static_cast<const f16*>(x),
                        static_cast<f16*>(y), batch, c, h, w, focus, y_ld);
     Y5_LAUNCH_CHECK("pack_image_kernel");
+    return Y5_OK;
+}
+
+int y5_launch_normalize_u8(const void* x, void* y, long long n, hipStream_t s) {
+    Y5_REQUIRE(n >= 0 && (n == 0 || (x && y)), "normalize_u8: null pointer");
+    if (n == 0) return Y5_OK;
+    Y5_REQUIRE(y5_aligned16(x) && y5_aligned16(y), "normalize_u8: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(normalize_u8_kernel, dim3(grid_for((n + 15) / 16)), dim3(kThreads), 0, s, static_cast<const uint8_t*>(x),
+                       static_cast<f16*>(y), n);
+    Y5_LAUNCH_CHECK("normalize_u8_kernel");
     return Y5_OK;
 }
 

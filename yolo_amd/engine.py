@@ -63,7 +63,14 @@ def eligible(model, x):
     Detect.export off, 4-d input whose height and width are multiples of the largest stride."""
     if _DISABLED[0] or model.training or torch.is_grad_enabled():
         return False
-    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype is torch.float16 and x.dim() == 4):
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4):
+        return False
+    if x.dtype is torch.uint8:
+        # the data loader's tensor (utils/datasets.py:140-141): the engine applies img.half() / 255.0 (test.py:152-154)
+        # itself, inside the first kernel where it can; only meaningful for a half-precision model
+        if next(model.parameters()).dtype is not torch.float16:
+            return False
+    elif x.dtype is not torch.float16:
         return False
     from yolo_amd.models.yolo import Detect
     head = model.model[-1]
@@ -244,8 +251,10 @@ class Plan:
             d.act, d.slope = _lib.ACT_LEAKY, slope
         if image is not None:
             d.batch, d.h, d.w_in, d.cin, d.x_ld = image.shape[0], image.shape[2], image.shape[3], image.shape[1], 0
-            _lib.check(self.lib.y5_plan_add_focus_conv(self.handle, C.byref(d)))
-            self.labels.append('%s focus+conv3x3 %d->%d @%dx%d' % (label, x.c_log, out.c_log, ho, wo))
+            add = self.lib.y5_plan_add_focus_conv_u8 if image.dtype is torch.uint8 else self.lib.y5_plan_add_focus_conv
+            _lib.check(add(self.handle, C.byref(d)))
+            self.labels.append('%s %sfocus+conv3x3 %d->%d @%dx%d' % (label, 'u8/255+' if image.dtype is torch.uint8 else '',
+                                                                       x.c_log, out.c_log, ho, wo))
             return
         d.variant = self._tune(d, x)
         _lib.check(self.lib.y5_plan_add_conv(self.handle, C.byref(d)))
@@ -305,6 +314,16 @@ class Plan:
                 raise Unsupported('unfused Conv with conv bias')
             self._conv(label, x, m.conv, out, affine=bn_affine(m.bn), act=m.act, res=res, image=image)
 
+    def _as_f16(self, image):
+        """The NCHW input as fp16: itself, or for a uint8 input a buffer filled by a normalise op (x.half() / 255)."""
+        if image.dtype is not torch.uint8:
+            return image
+        out = torch.zeros(image.shape, dtype=torch.float16, device=self.device)
+        self.keep.append(out)
+        _lib.check(self.lib.y5_plan_add_normalize_u8(self.handle, image.data_ptr(), out.data_ptr(), image.numel()))
+        self.labels.append('input u8 -> f16 / 255')
+        return out
+
     def _focus(self, name, m, image, out):
         """models.common.Focus on the plan's input image (NCHW): one fused kernel when its convolution is the usual
         3x3 stride-1 over 3 image channels and at most 96 filters, else space-to-depth packing + convolution."""
@@ -315,6 +334,7 @@ class Plan:
             shape_only = Act(None, 0, segs[0][1], B, H // 2, W // 2, segs)
             self._conv_block(name, m.conv, shape_only, out, image=image)
             return
+        image = self._as_f16(image)
         packed = self._new_act(B, H // 2, W // 2, segs)
         _lib.check(self.lib.y5_plan_add_pack_image(self.handle, image.data_ptr(), packed.ptr, B, cin, H, W, 1, packed.ld))
         self.labels.append('%s pack focus' % name)
@@ -405,7 +425,7 @@ class Plan:
         # ---- pass 3: emit ops
         image = torch.zeros_like(x)  # stands for external slot 0 while recording
         self.keep.append(image)
-        _lib.check(self.lib.y5_plan_bind_slot(self.handle, 0, image.data_ptr(), image.numel() * 2))
+        _lib.check(self.lib.y5_plan_bind_slot(self.handle, 0, image.data_ptr(), image.numel() * image.element_size()))
         outs = [None] * len(layers)
         # Detect's convolutions of all but the last level only feed the final decode: with Y5_SIDE_STREAM=1 each is
         # recorded right after the layer it reads, on the plan's side stream, so that it runs beside the rest of the
@@ -435,6 +455,7 @@ class Plan:
             elif isinstance(m, common.Conv):
                 if i == 0:
                     xin = self._new_act(B, H, W, [(self.cin, pad8(self.cin))])
+                    image = self._as_f16(image)
                     _lib.check(self.lib.y5_plan_add_pack_image(self.handle, image.data_ptr(), xin.ptr, B, self.cin, H, W, 0, xin.ld))
                     self.labels.append('%s pack nchw' % name)
                 else:
@@ -722,7 +743,7 @@ class Engine:
                 p.close()
             self.plans.clear()
             self.signature = sig
-        key = (tuple(x.shape), x.device.index)
+        key = (tuple(x.shape), x.device.index, x.dtype)
         plan = self.plans.get(key)
         if plan is None:
             if self.unsupported is not None and self.unsupported[0] == (sig, key):

@@ -113,6 +113,8 @@ class Model(nn.Module):
         from yolo_amd import engine
         if not profile and engine.eligible(self, x):
             return engine.run(self, x)
+        if isinstance(x, torch.Tensor) and x.dtype is torch.uint8:  # same convenience off the engine: test.py:152-154
+            x = x.to(next(self.parameters()).dtype) / 255.0
         return self._forward_modules(x, profile)
 
     def _forward_modules(self, x, profile=False):
