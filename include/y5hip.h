@@ -205,6 +205,14 @@ typedef struct y5_nms_desc {
 size_t y5_nms_workspace_bytes(int batch, int max_candidates);
 int y5_nms_batched(const y5_nms_desc* d, y5_stream_t stream);
 
+/* Rescale the kept boxes from the network's input size to each original image and clip them, in place, without a host
+ * round trip.  Replaces: scale_coords + clip_coords  utils/utils.py:193-214 (called per image at detect.py:93 and
+ * test.py:206,231), applied to the padded block that y5_nms_batched wrote: det (batch, max_det, row_floats) fp32 with
+ * xyxy in floats 0..3, count[b] valid rows per image; params (batch, 5) fp32 = {pad_x, pad_y, gain, img0_w, img0_h} as
+ * the reference computes them (or takes them from ratio_pad).  do_round != 0 adds detect.py's .round(). */
+int y5_scale_coords_f32(float* det, const int32_t* count, const float* params, int batch, int max_det, int row_floats,
+                        int do_round, y5_stream_t stream);
+
 /* Greedy NMS of one box set, the drop-in for torchvision.ops.boxes.nms(boxes, scores, iou_thres)
  * (call site utils/utils.py:627; also used by the merge=True branch utils/utils.py:630-639).
  * boxes (n,4) fp32 corner boxes, scores (n) fp32.  keep (max_keep) int64 receives the kept indices

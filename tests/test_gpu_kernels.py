@@ -253,6 +253,39 @@ def test_nms_sort_paths_by_candidate_count(dev):
         assert np.array_equal(det[b, :len(ridx)].cpu().numpy(), rdet)
 
 
+def test_scale_detections_equals_the_reference_statements(dev):
+    """y5_scale_coords_f32 against scale_coords + clip_coords (utils/utils.py:193-214) executed by torch on the CPU,
+    per image, on boxes that reach beyond the letterbox padding; with and without ratio_pad and detect.py's round."""
+    g = torch.Generator().manual_seed(8)
+    img1 = (384, 640)
+    img0 = [(480, 640, 3), (1080, 1920, 3), (333, 517, 3), (640, 384, 3)]
+    B, max_det = len(img0), 300
+    det = torch.zeros(B, max_det, 6)
+    det[..., :2] = torch.rand(B, max_det, 2, generator=g) * 700 - 30
+    det[..., 2:4] = det[..., :2] + torch.rand(B, max_det, 2, generator=g) * 300
+    det[..., 4] = torch.rand(B, max_det, generator=g)
+    count = torch.tensor([300, 17, 0, 255], dtype=torch.int32)
+    rps = [None, ((0.333, 0.333), (0.5, 12.0)), None, None]
+    for rnd in (False, True):
+        ref = det.clone()
+        for b in range(B):
+            c = ref[b, :count[b], :4]          # a view: the statements below are the reference's, in place
+            if rps[b] is None:
+                gain = min(img1[0] / img0[b][0], img1[1] / img0[b][1])
+                pad = (img1[1] - img0[b][1] * gain) / 2, (img1[0] - img0[b][0] * gain) / 2
+            else:
+                gain, pad = rps[b][0][0], rps[b][1]
+            c[:, [0, 2]] -= pad[0]
+            c[:, [1, 3]] -= pad[1]
+            c[:, :4] /= gain
+            c[:, 0].clamp_(0, img0[b][1]); c[:, 1].clamp_(0, img0[b][0])
+            c[:, 2].clamp_(0, img0[b][1]); c[:, 3].clamp_(0, img0[b][0])
+            if rnd:
+                ref[b, :count[b], :4] = c.round()
+        got = hip_nms.scale_detections(det.clone().to(dev), count.to(dev), img1, img0, rps, round_=rnd)
+        assert torch.equal(got.cpu().view(torch.int32), ref.view(torch.int32))
+
+
 def test_box_nms_primitive_and_merge_path(dev):
     g = torch.Generator().manual_seed(0)
     xy = torch.rand(3000, 2, generator=g) * 300

@@ -478,6 +478,25 @@ __global__ __launch_bounds__(256) void nms_clear_tail_kernel(float* det, int* ke
         for (int i = c + threadIdx.x; i < max_det; i += 256) kept_index[(long long)b * max_det + i] = -1;
 }
 
+// scale_coords + clip_coords (utils/utils.py:193-214) on the padded detection block, in place: one thread per row.
+// params[b] = {pad_x, pad_y, gain, img0_w, img0_h}.  Same fp32 operations in the same order as the reference's tensor
+// statements: subtract the padding, divide by the gain, clamp.
+__global__ __launch_bounds__(256) void scale_coords_kernel(float* __restrict__ det, const int* __restrict__ count,
+                                                           const float* __restrict__ params, int max_det, int row_floats, int do_round) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= count[b] || i >= max_det) return;
+    const float px = params[b * 5 + 0], py = params[b * 5 + 1], gain = params[b * 5 + 2];
+    const float w0 = params[b * 5 + 3], h0 = params[b * 5 + 4];
+    float* r = det + ((long long)b * max_det + i) * row_floats;
+    float x1 = __fdiv_rn(__fsub_rn(r[0], px), gain), y1 = __fdiv_rn(__fsub_rn(r[1], py), gain);
+    float x2 = __fdiv_rn(__fsub_rn(r[2], px), gain), y2 = __fdiv_rn(__fsub_rn(r[3], py), gain);
+    x1 = fminf(fmaxf(x1, 0.f), w0); y1 = fminf(fmaxf(y1, 0.f), h0);
+    x2 = fminf(fmaxf(x2, 0.f), w0); y2 = fminf(fmaxf(y2, 0.f), h0);
+    if (do_round) { x1 = rintf(x1); y1 = rintf(y1); x2 = rintf(x2); y2 = rintf(y2); }
+    r[0] = x1; r[1] = y1; r[2] = x2; r[3] = y2;
+}
+
 int pow2_at_least(int v) {
     int p = 64;
     while (p < v) p <<= 1;
@@ -579,6 +598,16 @@ extern "C" int y5_nms_batched(const y5_nms_desc* d, y5_stream_t stream) {
     Y5_LAUNCH_CHECK("nms_select_kernel");
     hipLaunchKernelGGL(nms_clear_tail_kernel, dim3((unsigned)d->batch), dim3(256), 0, s, d->det, d->kept_index, d->count, d->max_det);
     Y5_LAUNCH_CHECK("nms_clear_tail_kernel");
+    return Y5_OK;
+}
+
+extern "C" int y5_scale_coords_f32(float* det, const int32_t* count, const float* params, int batch, int max_det, int row_floats,
+                                   int do_round, y5_stream_t stream) {
+    Y5_REQUIRE(det && count && params, "scale_coords: null pointer");
+    Y5_REQUIRE(batch > 0 && max_det > 0 && row_floats >= 4, "scale_coords: bad shape (%d, %d, %d)", batch, max_det, row_floats);
+    hipLaunchKernelGGL(scale_coords_kernel, dim3((unsigned)((max_det + 255) / 256), (unsigned)batch), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), det, count, params, max_det, row_floats, do_round);
+    Y5_LAUNCH_CHECK("scale_coords_kernel");
     return Y5_OK;
 }
 

@@ -94,3 +94,29 @@ def nms(boxes, scores, iou_thres, max_keep=MAX_DET):
         _lib.check(lib.y5_nms_boxes_f32(boxes.data_ptr(), scores.data_ptr(), n, float(iou_thres), keep.data_ptr(),
                                         cnt.data_ptr(), max_keep, ws.data_ptr(), ws_bytes, _lib.current_stream()))
     return keep[:int(cnt.item())]
+
+
+def scale_detections(det, count, img1_shape, img0_shapes, ratio_pads=None, round_=False):
+    """scale_coords + clip_coords (reference: utils/utils.py:193-214) for a whole padded batch, in place on the GPU.
+    det (B, max_det, 6) fp32 and count (B,) as returned by nms_padded; img1_shape = (h, w) of the network input;
+    img0_shapes[b] = (h, w, ...) of original image b; ratio_pads[b] = ((gain, ...), (pad_x, pad_y)) or None, exactly
+    the reference's ratio_pad argument.  round_=True adds detect.py:93's .round().  Returns det."""
+    B, max_det, nf = det.shape
+    if det.dtype is not torch.float32 or not det.is_cuda or not det.is_contiguous():
+        raise ValueError('scale_detections expects a contiguous fp32 CUDA tensor')
+    rows = []
+    for b in range(B):
+        s0 = img0_shapes[b]
+        rp = None if ratio_pads is None else ratio_pads[b]
+        if rp is None:  # calculate from img0_shape
+            gain = min(img1_shape[0] / s0[0], img1_shape[1] / s0[1])
+            pad = (img1_shape[1] - s0[1] * gain) / 2, (img1_shape[0] - s0[0] * gain) / 2
+        else:
+            gain = rp[0][0]
+            pad = rp[1]
+        rows.append([pad[0], pad[1], gain, s0[1], s0[0]])
+    params = torch.tensor(rows, dtype=torch.float64).to(torch.float32).to(det.device)
+    with torch.cuda.device(det.device):
+        _lib.check(_lib.lib().y5_scale_coords_f32(det.data_ptr(), count.data_ptr(), params.data_ptr(), B, max_det, nf,
+                                                   int(bool(round_)), _lib.current_stream()))
+    return det
