@@ -205,6 +205,17 @@ typedef struct y5_nms_desc {
 size_t y5_nms_workspace_bytes(int batch, int max_candidates);
 int y5_nms_batched(const y5_nms_desc* d, y5_stream_t stream);
 
+/* Prediction <-> label matching of the evaluation loop, for a whole batch, without a host round trip.
+ * Replaces: test.py:199 (clip_coords(pred, (height, width)), done in place on det) and test.py:220-247 (per class:
+ * box_iou(pred, tbox).max(1), predictions in confidence order claim their best label once, correct = iou > iouv).
+ * det (batch, max_det, row_floats >= 6) fp32 rows xyxy, conf, cls with count[b] valid rows, as y5_nms_batched wrote
+ * them; targets (n_targets, 6) fp32 rows {image index, class, x, y, w, h normalised} (the data loader's `targets`);
+ * iouv (niou <= 16) fp32; correct (batch, max_det, niou) bytes, 0/1, rows past count[b] zero; overflow (batch) int32 or
+ * NULL: set to 1 for an image with more than 2048 labels (the excess is ignored). */
+int y5_match_predictions_f32(float* det, const int32_t* count, const float* targets, int n_targets, const float* iouv, int niou,
+                             uint8_t* correct, int32_t* overflow, int batch, int max_det, int row_floats, float height, float width,
+                             y5_stream_t stream);
+
 /* Rescale the kept boxes from the network's input size to each original image and clip them, in place, without a host
  * round trip.  Replaces: scale_coords + clip_coords  utils/utils.py:193-214 (called per image at detect.py:93 and
  * test.py:206,231), applied to the padded block that y5_nms_batched wrote: det (batch, max_det, row_floats) fp32 with

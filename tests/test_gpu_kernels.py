@@ -286,6 +286,57 @@ def test_scale_detections_equals_the_reference_statements(dev):
         assert torch.equal(got.cpu().view(torch.int32), ref.view(torch.int32))
 
 
+@pytest.mark.parametrize('name', ['a', 'b', 'c'])
+def test_match_predictions_equals_the_reference_fixture(dev, name):
+    """y5_match_predictions_f32 (clip + best-IoU matching of a whole batch in one launch) against the fixture computed
+    with the reference's box_iou / xywh2xyxy / clip_coords: correct flags and the clipped boxes bit for bit."""
+    from yolo_amd import metrics
+    z = util.golden('metrics_match_' + name)
+    det = torch.from_numpy(z['det']).to(dev)
+    count = torch.from_numpy(z['count']).to(dev)
+    correct = metrics.match_predictions(det, count, torch.from_numpy(z['targets']), float(z['height']), float(z['width']),
+                                        torch.from_numpy(z['iouv']), check_overflow=True)
+    assert np.array_equal(correct.cpu().numpy(), z['correct'])
+    for b in range(det.shape[0]):
+        n = int(z['count'][b])
+        assert np.array_equal(det[b, :n].cpu().numpy().view(np.int32), z['clipped'][b, :n].view(np.int32))
+    stats = metrics.batch_stats(det, count, correct, torch.from_numpy(z['targets']))
+    assert sum(s[0].shape[0] for s in stats) == int(z['count'].sum())
+
+
+def test_match_predictions_large_random_batch_against_oracle(dev):
+    from oracle import metrics_ref
+    from yolo_amd import metrics
+    g = torch.Generator().manual_seed(21)
+    B, h, w = 16, 640, 640
+    labels = []
+    det = torch.zeros(B, 300, 6)
+    count = torch.randint(0, 301, (B,), generator=g, dtype=torch.int32)
+    for b in range(B):
+        nl = int(torch.randint(0, 90, (1,), generator=g))
+        cxy, wh = torch.rand(nl, 2, generator=g) * 0.8 + 0.1, torch.rand(nl, 2, generator=g) * 0.3 + 0.02
+        cls = torch.randint(0, 6, (nl, 1), generator=g).float()
+        labels.append(torch.cat((torch.full((nl, 1), float(b)), cls, cxy, wh), 1))
+        n = int(count[b])
+        if nl and n:
+            t = torch.randint(0, nl, (n,), generator=g)
+            c = torch.cat((cxy[t] - wh[t] / 2, cxy[t] + wh[t] / 2), 1) * torch.tensor([w, h, w, h])
+            det[b, :n, :4] = c + (torch.rand(n, 4, generator=g) - 0.5) * 40
+            det[b, :n, 5] = torch.where(torch.rand(n, generator=g) < 0.8, cls[t, 0], torch.randint(0, 6, (n,), generator=g).float())
+        det[b, :n, 4] = torch.sort(torch.rand(n, generator=g), descending=True).values
+    targets = torch.cat(labels, 0)
+    iouv = torch.linspace(0.5, 0.95, 10)
+    ref_det = det.clone()
+    ref = torch.zeros(B, 300, 10, dtype=torch.bool)
+    for b in range(B):
+        n = int(count[b])
+        ref[b, :n] = metrics_ref.match_image(ref_det[b, :n], targets[targets[:, 0] == b, 1:], float(h), float(w), iouv)
+    d = det.to(dev)
+    got = metrics.match_predictions(d, count.to(dev), targets, h, w, iouv)
+    assert torch.equal(got.cpu(), ref) and bool(ref.any())
+    assert torch.equal(d.cpu().view(torch.int32), ref_det.view(torch.int32))
+
+
 def test_box_nms_primitive_and_merge_path(dev):
     g = torch.Generator().manual_seed(0)
     xy = torch.rand(3000, 2, generator=g) * 300

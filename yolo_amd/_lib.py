@@ -64,6 +64,8 @@ SIGNATURES = {
     'y5_sigmoid_f16': (_i, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, _s]),
     'y5_nms_workspace_bytes': (C.c_size_t, [_i, _i]),
     'y5_nms_batched': (_i, [C.POINTER(NmsDesc), _s]),
+    'y5_match_predictions_f32': (_i, [C.c_void_p, C.c_void_p, C.c_void_p, _i, C.c_void_p, _i, C.c_void_p, C.c_void_p, _i, _i, _i,
+                                      C.c_float, C.c_float, _s]),
     'y5_scale_coords_f32': (_i, [C.c_void_p, C.c_void_p, C.c_void_p, _i, _i, _i, _i, _s]),
     'y5_nms_boxes_f32': (_i, [_p, _p, _i, C.c_double, _p, _p, _i, _p, C.c_size_t, _s]),
     'y5_plan_create': (_i, [C.POINTER(_p)]),

@@ -497,6 +497,105 @@ __global__ __launch_bounds__(256) void scale_coords_kernel(float* __restrict__ d
     r[0] = x1; r[1] = y1; r[2] = x2; r[3] = y2;
 }
 
+// ------------------------------------------------------------------------------------------
+// Prediction <-> target matching of the evaluation loop (test.py:199, 220-247), one workgroup per image.
+// ------------------------------------------------------------------------------------------
+constexpr int MATCH_THREADS = 256;
+constexpr int MATCH_MAX_TARGETS = 2048;   // labels of one image held in LDS
+constexpr int MATCH_MAX_IOU = 16;
+
+struct MatchArgs {
+    float* det;            // (B, max_det, row_floats): xyxy, conf, cls -- clipped in place like the reference does
+    const int* count;      // (B,)
+    const float* targets;  // (T, 6): image index, class, x, y, w, h (normalised), the reference's `targets`
+    const float* iouv;     // (niou,)
+    unsigned char* correct;  // (B, max_det, niou)
+    int* overflow;         // (B,) set to 1 when an image has more than MATCH_MAX_TARGETS labels (may be null)
+    int n_targets, max_det, row_floats, niou;
+    float width, height;
+};
+
+__global__ __launch_bounds__(MATCH_THREADS) void match_kernel(const MatchArgs a) {
+    __shared__ float tcls[MATCH_MAX_TARGETS];
+    __shared__ Box tbox[MATCH_MAX_TARGETS];
+    __shared__ unsigned char detected[MATCH_MAX_TARGETS];
+    __shared__ float best_iou[MAX_DET_CAP];
+    __shared__ int best_t[MAX_DET_CAP];
+    __shared__ int nl_s;
+
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int n = min(a.count[b], a.max_det);
+    float* det = a.det + (long long)b * a.max_det * a.row_floats;
+    unsigned char* correct = a.correct + (long long)b * a.max_det * a.niou;
+    for (int i = tid; i < a.max_det * a.niou; i += MATCH_THREADS) correct[i] = 0;
+
+    // labels of this image, in their original order (the order decides which of two equal IoUs wins): wave 0 compacts
+    if (tid < 64) {
+        int nl = 0;
+        for (int t0 = 0; t0 < a.n_targets; t0 += 64) {
+            const int t = t0 + lane;
+            const bool mine = t < a.n_targets && a.targets[(long long)t * 6] == (float)b;
+            const u64 m = __ballot(mine);
+            const int pos = nl + __builtin_popcountll(m & ((1ull << lane) - 1));
+            if (mine && pos < MATCH_MAX_TARGETS) {
+                const float* r = a.targets + (long long)t * 6;
+                // xywh2xyxy(labels[:, 1:5]) * whwh: centre -/+ half size, then scaled to pixels (utils/utils.py:183-190)
+                const float hw = r[4] / 2.f, hh = r[5] / 2.f;
+                tcls[pos] = r[1];
+                tbox[pos] = {__fmul_rn(__fsub_rn(r[2], hw), a.width), __fmul_rn(__fsub_rn(r[3], hh), a.height),
+                             __fmul_rn(__fadd_rn(r[2], hw), a.width), __fmul_rn(__fadd_rn(r[3], hh), a.height)};
+                detected[pos] = 0;
+            }
+            nl += __builtin_popcountll(m);
+        }
+        if (lane == 0) {
+            if (a.overflow) a.overflow[b] = nl > MATCH_MAX_TARGETS;
+            nl_s = nl < MATCH_MAX_TARGETS ? nl : MATCH_MAX_TARGETS;
+        }
+    }
+    __syncthreads();
+    const int nl = nl_s;
+
+    // clip_coords(pred, (height, width)) and, per prediction, the best IoU over the labels of its class (first maximum)
+    for (int p = tid; p < n; p += MATCH_THREADS) {
+        float* r = det + (long long)p * a.row_floats;
+        Box pb = {fminf(fmaxf(r[0], 0.f), a.width), fminf(fmaxf(r[1], 0.f), a.height), fminf(fmaxf(r[2], 0.f), a.width),
+                  fminf(fmaxf(r[3], 0.f), a.height)};
+        r[0] = pb.x1; r[1] = pb.y1; r[2] = pb.x2; r[3] = pb.y2;
+        const float pc = r[5];
+        const float parea = __fmul_rn(__fsub_rn(pb.x2, pb.x1), __fsub_rn(pb.y2, pb.y1));
+        float best = -1.f;
+        int bt = -1;
+        for (int t = 0; t < nl; ++t) {
+            if (tcls[t] != pc) continue;
+            const Box tb = tbox[t];
+            // box_iou (utils/utils.py:355-377): clamped width * clamped height over the union, all fp32
+            const float w = fmaxf(__fsub_rn(fminf(pb.x2, tb.x2), fmaxf(pb.x1, tb.x1)), 0.f);
+            const float h = fmaxf(__fsub_rn(fminf(pb.y2, tb.y2), fmaxf(pb.y1, tb.y1)), 0.f);
+            const float inter = __fmul_rn(w, h);
+            const float tarea = __fmul_rn(__fsub_rn(tb.x2, tb.x1), __fsub_rn(tb.y2, tb.y1));
+            const float iou = __fdiv_rn(inter, __fsub_rn(__fadd_rn(parea, tarea), inter));
+            if (iou > best) { best = iou; bt = t; }
+        }
+        best_iou[p] = best;
+        best_t[p] = bt;
+    }
+    __syncthreads();
+
+    // predictions claim labels in their (descending-confidence) order; a label is claimed once
+    if (tid == 0) {
+        const float thr0 = a.iouv[0];
+        int found = 0;
+        for (int p = 0; p < n && found < nl; ++p) {
+            const int t = best_t[p];
+            if (t < 0 || !(best_iou[p] > thr0) || detected[t]) continue;
+            detected[t] = 1;
+            ++found;
+            for (int k = 0; k < a.niou; ++k) correct[p * a.niou + k] = best_iou[p] > a.iouv[k];
+        }
+    }
+}
+
 int pow2_at_least(int v) {
     int p = 64;
     while (p < v) p <<= 1;
@@ -608,6 +707,22 @@ extern "C" int y5_scale_coords_f32(float* det, const int32_t* count, const float
     hipLaunchKernelGGL(scale_coords_kernel, dim3((unsigned)((max_det + 255) / 256), (unsigned)batch), dim3(256), 0,
                        static_cast<hipStream_t>(stream), det, count, params, max_det, row_floats, do_round);
     Y5_LAUNCH_CHECK("scale_coords_kernel");
+    return Y5_OK;
+}
+
+extern "C" int y5_match_predictions_f32(float* det, const int32_t* count, const float* targets, int n_targets, const float* iouv, int niou,
+                                        uint8_t* correct, int32_t* overflow, int batch, int max_det, int row_floats, float height,
+                                        float width, y5_stream_t stream) {
+    Y5_REQUIRE(det && count && iouv && correct, "match: null pointer");
+    Y5_REQUIRE(n_targets >= 0 && (n_targets == 0 || targets), "match: null targets");
+    Y5_REQUIRE(batch > 0 && max_det > 0 && max_det <= MAX_DET_CAP && row_floats >= 6, "match: bad shape (%d, %d, %d)", batch, max_det, row_floats);
+    Y5_REQUIRE(niou >= 1 && niou <= MATCH_MAX_IOU, "match: niou %d out of range 1..%d", niou, MATCH_MAX_IOU);
+    MatchArgs a;
+    a.det = det; a.count = count; a.targets = targets; a.iouv = iouv; a.correct = correct; a.overflow = overflow;
+    a.n_targets = n_targets; a.max_det = max_det; a.row_floats = row_floats; a.niou = niou;
+    a.width = width; a.height = height;
+    hipLaunchKernelGGL(match_kernel, dim3((unsigned)batch), dim3(MATCH_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    Y5_LAUNCH_CHECK("match_kernel");
     return Y5_OK;
 }
 
