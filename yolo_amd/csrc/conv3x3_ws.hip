@@ -292,10 +292,11 @@ int launch_ws3m(WsArgs a, hipStream_t s) {
     // a configuration that leaves room for only one workgroup per CU has registers to spare: fetch two tiles ahead
     constexpr int DEPTH = lds > 80 * 1024 ? 2 : 1;
     auto kern = conv3x3_ws_kernel<CIN, BN, STRIDE, MODE, DEPTH>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_set{0};  // one bit per device: the attribute is per function and device
+    const unsigned long long attr_set_bit = 1ull << y5_current_device();
+    if (!(attr_set.load() & attr_set_bit)) {
         Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set.fetch_or(attr_set_bit);
     }
     a.tiles_n = (a.Cout + BN - 1) / BN;
     const int per_cu = (int)((160 * 1024) / lds) > 2 ? 2 : (int)((160 * 1024) / lds);

@@ -214,10 +214,11 @@ template <int RN, bool U8>
 int launch_focus(const FocusArgs& a, hipStream_t s) {
     constexpr int CN = RN * 32;
     constexpr size_t lds = (size_t)CN * kWPitch * 2 + 2 * kPatchBuf * 4 + 4 * 32 * (CN * 2 + 16) + 3 * CN * 4 + 256 * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_set{0};  // one bit per device: the attribute is per function and device
+    const unsigned long long attr_set_bit = 1ull << y5_current_device();
+    if (!(attr_set.load() & attr_set_bit)) {
         Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(focus_conv_kernel<RN, U8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set.fetch_or(attr_set_bit);
     }
     const int per_cu = RN == 1 ? 4 : RN == 2 ? 3 : 2;
     const int grid = a.ntiles < 256 * per_cu ? a.ntiles : 256 * per_cu;

@@ -237,10 +237,11 @@ int launch_halo(ConvArgs a, hipStream_t s) {
     a.tiles_total = (int)total;
     constexpr int ring = 2 * HALO_BYTES + 3 * 3 * BN * REC, ep = HBM_ * (BN * 2 + 16);
     constexpr int smem = (ring > ep ? ring : ep) + 3 * BN * 4;
-    static bool attr_set = false;  // per process
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_set{0};  // one bit per device: the attribute is per function and device
+    const unsigned long long attr_set_bit = 1ull << y5_current_device();
+    if (!(attr_set.load() & attr_set_bit)) {
         Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo3x3_kernel<BN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
+        attr_set.fetch_or(attr_set_bit);
     }
     hipLaunchKernelGGL((conv_halo3x3_kernel<BN, WM, WN>), dim3((unsigned)total), dim3(256), smem, s, a);
     Y5_LAUNCH_CHECK("conv_halo3x3_kernel");

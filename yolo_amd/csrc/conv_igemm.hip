@@ -333,8 +333,9 @@ int launch_tile(const ConvArgs& a0, int ksize, bool direct, hipStream_t s) {
     a.tiles_total = (int)total;
     typedef IgemmCfg<BM, BN, WM, WN, S, BK> Cfg;
     const dim3 grid((unsigned)total), block(Cfg::NT);
-    static bool attr_set = false;  // per process; LDS beyond 64 KiB has to be asked for once per kernel
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_set{0};  // one bit per device: the attribute is per function and device
+    const unsigned long long attr_set_bit = 1ull << y5_current_device();
+    if (!(attr_set.load() & attr_set_bit)) {
         Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, 3, S, BK, false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
         Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, 3, S, BK, false, true>),
@@ -343,7 +344,7 @@ int launch_tile(const ConvArgs& a0, int ksize, bool direct, hipStream_t s) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
         Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, 1, S, BK, false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
-        attr_set = true;
+        attr_set.fetch_or(attr_set_bit);
     }
     if (ksize == 3 && a.Cin % BK == 0 && !getenv("Y5_NO_UT"))
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 3, S, BK, false, true>), grid, block, Cfg::SMEM, s, a);

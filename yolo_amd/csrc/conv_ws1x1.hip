@@ -186,11 +186,12 @@ int launch_ws(ConvArgs a, hipStream_t s) {
     constexpr int WTN = BN / WN;
     constexpr size_t lds = (size_t)BN * KP * 2 + (size_t)NST * BM * KP * 2 + 4 * 32 * (WTN * 2 + 16) + 3 * BN * 4;
     static_assert(lds <= 160 * 1024, "configuration does not fit in LDS");
-    static bool attr_set = false;
+    static std::atomic<unsigned long long> attr_set{0};  // one bit per device: the attribute is per function and device
+    const unsigned long long attr_set_bit = 1ull << y5_current_device();
     auto kern = conv_ws1x1_kernel<BM, BN, WM, WN, KP, NST>;
-    if (!attr_set) {
+    if (!(attr_set.load() & attr_set_bit)) {
         Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set.fetch_or(attr_set_bit);
     }
     a.tiles_n = (a.Cout + BN - 1) / BN;
     const long long tiles_m = (a.M + BM - 1) / BM;

@@ -603,11 +603,12 @@ int pow2_at_least(int v) {
 }
 
 int ensure_sort_lds() {
-    static bool done = false;  // per process; the attribute is per function and idempotent
-    if (!done) {
+    static std::atomic<unsigned long long> done{0};  // one bit per device: the attribute is per function and device
+    const unsigned long long done_bit = 1ull << y5_current_device();
+    if (!(done.load() & done_bit)) {
         Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    SORT_LDS_KEYS * (int)sizeof(u64)));
-        done = true;
+        done.fetch_or(done_bit);
     }
     return Y5_OK;
 }
@@ -669,11 +670,12 @@ extern "C" int y5_nms_batched(const y5_nms_desc* d, y5_stream_t stream) {
     const dim3 cgrid((unsigned)((d->n_rows + CAND_ROWS - 1) / CAND_ROWS), (unsigned)d->batch);
     const size_t tile_bytes = ((size_t)CAND_ROWS * d->no * (d->pred_dtype == 0 ? 2 : 4) + 15) / 16 * 16;
     Y5_REQUIRE(tile_bytes <= 150 * 1024, "nms: %d values per row do not fit the staging tile", d->no);
-    static bool cand_attr = false;  // per process: the staging tile may exceed the default 64 KiB of dynamic LDS
-    if (!cand_attr) {
+    static std::atomic<unsigned long long> cand_attr{0};  // one bit per device: the attribute is per function and device
+    const unsigned long long cand_attr_bit = 1ull << y5_current_device();
+    if (!(cand_attr.load() & cand_attr_bit)) {
         Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_candidates_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_candidates_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        cand_attr = true;
+        cand_attr.fetch_or(cand_attr_bit);
     }
     if (d->pred_dtype == 0)
         hipLaunchKernelGGL(nms_candidates_kernel<f16>, cgrid, dim3(CAND_THREADS), tile_bytes, s, static_cast<const f16*>(d->pred),

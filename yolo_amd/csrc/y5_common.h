@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/y5hip.h"
 
 typedef _Float16 f16;
@@ -33,6 +35,13 @@ int y5_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3))
         hipError_t e_ = hipGetLastError();                                                         \
         if (e_ != hipSuccess) return y5_fail(Y5_EHIP, "launch %s -> %s", name, hipGetErrorString(e_)); \
     } while (0)
+
+// Ordinal of the current device, folded into 0..63 (index of the per-device "done once" bits).
+static inline int y5_current_device() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return d & 63;
+}
 
 static inline bool y5_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
