@@ -59,7 +59,7 @@ def run_conv(dev, x, w, bias=None, scale=None, shift=None, slope=None, res=None,
     xn = torch.zeros(B, H, W, cip, dtype=torch.float16, device=dev)
     xn[..., :Ci] = x.permute(0, 2, 3, 1)
     kk = k * k * cip
-    kpad, rows = (kk + 63) // 64 * 64, (Co + 127) // 128 * 128
+    kpad, rows = (kk + 63) // 64 * 64, (Co + 255) // 256 * 256
     wp = torch.zeros(rows, kpad, dtype=torch.float16, device=dev)
     wv = torch.zeros(Co, k, k, cip, dtype=torch.float16, device=dev)
     wv[..., :Ci] = w.permute(0, 2, 3, 1)
@@ -147,6 +147,7 @@ VARIANT_SHAPES = [
     (3, 32, 64, 50, 38, 3, 2),
     (2, 64, 64, 33, 47, 3, 1),
     (2, 32, 24, 64, 64, 3, 1),
+    (2, 160, 320, 12, 20, 3, 1),
 ]
 
 

@@ -14,7 +14,7 @@ cip, cop = (Ci + 7) // 8 * 8, (Co + 7) // 8 * 8
 Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
 x = torch.randn(B, H, W, cip, device=dev).half()
 kk = k * k * cip
-kpad, rows = (kk + 63) // 64 * 64, (Co + 127) // 128 * 128
+kpad, rows = (kk + 63) // 64 * 64, (Co + 255) // 256 * 256
 w = torch.zeros(rows, kpad, dtype=torch.float16, device=dev)
 w[:Co, :kk] = (torch.randn(Co, kk, device=dev) / kk ** 0.5).half()
 y = torch.zeros(B, Ho, Wo, cop, dtype=torch.float16, device=dev)

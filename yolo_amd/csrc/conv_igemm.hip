@@ -378,6 +378,8 @@ const Variant kVariants[] = {
     Y5_V(128, 64, 4, 2, 2, 64),  Y5_V(128, 64, 4, 2, 3, 64),  Y5_V(64, 128, 2, 4, 2, 64),  Y5_V(64, 128, 2, 4, 3, 64),
     // tall tiles for narrow layers: the weight tile is a smaller share of what every K-step stages
     Y5_V(256, 64, 4, 2, 2, 64),  Y5_V(256, 64, 4, 2, 3, 32),  Y5_V(256, 32, 8, 1, 2, 64),  Y5_V(256, 32, 8, 1, 3, 32),
+    // 256 x 256: 128 MFMA FLOP per staged byte, for layers with enough pixels and channels to fill the chip with such tiles
+    Y5_V(256, 256, 2, 4, 3, 32), Y5_V(256, 256, 2, 4, 2, 64), Y5_V(256, 256, 4, 2, 2, 64),
 };
 #undef Y5_V
 constexpr int kNumIgemm = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
@@ -451,7 +453,13 @@ int y5_launch_conv(const y5_conv_desc& d, hipStream_t s) {
     a.div_cin = make_fastdiv((unsigned)d.cin);
     const bool direct = d.ksize == 1 && d.stride == 1;
 
-    if (d.variant > 0) return kVariants[d.variant - 1].launch(a, d.ksize, direct, s);
+    if (d.variant > 0) {
+        // a tile reads BN whole weight rows: the packed weights (rows padded to a multiple of 128) must hold them
+        const int bn = kVariants[d.variant - 1].bn;
+        if ((long long)((d.cout + bn - 1) / bn) * bn > d.w_rows)
+            return y5_fail(Y5_EINVAL, "conv: variant %d reads %d-row weight tiles, w_rows %d is too small for cout %d", d.variant, bn, d.w_rows, d.cout);
+        return kVariants[d.variant - 1].launch(a, d.ksize, direct, s);
+    }
 
     // Rule-based choice. Channel width: the widest of {128, 64, 32} that wastes the fewest padded channels.
     // Pixel height: 128 rows unless that leaves the 256 CUs with fewer than ~4 workgroups each, in which

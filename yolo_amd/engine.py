@@ -185,13 +185,13 @@ class Plan:
         return out
 
     def _pack_weight(self, weights, segs):
-        """Row groups [(weight (c, Cin_logical, k, k), padded rows)] -> fp16 [rows128][kpad64];
+        """Row groups [(weight (c, Cin_logical, k, k), padded rows)] -> fp16 [rows256][kpad64];
         K index (r*k + q)*cin_pad + c following the input tensor's channel `segs`."""
         k = weights[0][0].shape[-1]
         cin_pad = sum(p for _, p in segs)
         cin_log = sum(c for c, _ in segs)
         total_rows = sum(p for _, p in weights)
-        rows = (total_rows + 127) // 128 * 128
+        rows = (total_rows + 255) // 256 * 256   # whole 256-row weight tiles for the widest kernel variant
         kk = k * k * cin_pad
         kpad = (kk + 63) // 64 * 64
         packed = torch.zeros(rows, kpad, dtype=torch.float16, device=self.device)
