@@ -380,6 +380,8 @@ const Variant kVariants[] = {
     Y5_V(256, 64, 4, 2, 2, 64),  Y5_V(256, 64, 4, 2, 3, 32),  Y5_V(256, 32, 8, 1, 2, 64),  Y5_V(256, 32, 8, 1, 3, 32),
     // 256 x 256: 128 MFMA FLOP per staged byte, for layers with enough pixels and channels to fill the chip with such tiles
     Y5_V(256, 256, 2, 4, 3, 32), Y5_V(256, 256, 2, 4, 2, 64), Y5_V(256, 256, 4, 2, 2, 64),
+    // deeper rings on the big tiles: two K-steps (about 96 KB per CU) in flight cover the DMA round trip
+    Y5_V(256, 128, 4, 2, 3, 64), Y5_V(256, 128, 4, 2, 4, 32), Y5_V(256, 256, 2, 4, 4, 32), Y5_V(256, 64, 4, 2, 3, 64),
 };
 #undef Y5_V
 constexpr int kNumIgemm = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
