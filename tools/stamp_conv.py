@@ -40,7 +40,8 @@ e1.record()
 torch.cuda.synchronize()
 print('%.1f us per launch%s' % (e0.elapsed_time(e1) / 20 * 1e3, ' (staging only)' if os.environ.get('STAGING_ONLY') else ''))
 n = 65536
-if hasattr(lib, 'y5_debug_stamps3') and var >= 45:
+force = os.environ.get('STAMP_KIND')  # 'igemm' reads the im2col kernel's stamps whatever the variant id
+if hasattr(lib, 'y5_debug_stamps3') and var >= 45 and not force:
     buf = np.zeros((n, 8), dtype=np.uint64)
     assert lib.y5_debug_stamps3(buf.ctypes.data_as(C.c_void_p), n) == 0
     v = buf[buf[:, 6] > 0].astype(np.float64)
@@ -51,7 +52,7 @@ if hasattr(lib, 'y5_debug_stamps3') and var >= 45:
     print('  prologue       mean %9.0f;  whole kernel %9.0f' % (v[:, 5].mean(), v[:, 4].mean()))
     sys.exit(0)
 buf = np.zeros((n, 8), dtype=np.uint64)
-if 39 <= var <= 41:
+if 39 <= var <= 41 and not force:
     assert lib.y5_debug_stampsh(buf.ctypes.data_as(C.c_void_p), n) == 0
 else:
     assert lib.y5_debug_stamps(buf.ctypes.data_as(C.c_void_p), n) == 0
@@ -60,7 +61,7 @@ nk = v[0, 6]
 t0 = v[:, 5].min()
 span = (v[:, 5] + v[:, 3] + v[:, 4]).max() - t0
 print('variant %d: %d waves stamped, nk %d; kernel span %.0f cycles (100 MHz ticks?)' % (var, len(v), nk, span))
-for name, col in (('wait+barrier', 0), ('dma issue', 1), ('lds+mfma', 2), ('k loop total', 3), ('epilogue', 4)):
+for name, col in (('wait+barrier', 0), ('dma issue', 1), ('lds+mfma', 2), ('k loop total', 3), ('epilogue', 4), ('2nd barrier', 7)):
     print('  %-14s mean %9.0f  per step %8.1f   (p10 %.0f p90 %.0f)' % (name, v[:, col].mean(), v[:, col].mean() / nk,
                                                                     np.percentile(v[:, col], 10), np.percentile(v[:, col], 90)))
 print('  wave start spread: p50 %.0f p90 %.0f max %.0f' % tuple(np.percentile(v[:, 5] - t0, [50, 90, 100])))

@@ -39,6 +39,8 @@ struct ConvArgs {
     // halo-tile kernel only: output tiles per image and channel chunks
     int tiles_x, tiles_y, nchunks;
     FastDiv div_tpi, div_tx;
+    // loader-wave kernel, buffer addressing: bytes the x / w descriptors span
+    int x_bytes, w_bytes;
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -359,7 +359,7 @@ int launch_tile(const ConvArgs& a0, int ksize, bool direct, hipStream_t s) {
 }
 
 // Every compiled tile configuration. Index + 1 is the public variant id (0 = choose by rule); ids past the end
-// of this table select the halo-tile kernel's channel widths (conv_halo.hip).
+// of this table select the other kernel families in turn (conv_halo.hip, conv_ws1x1.hip, conv3x3_ws.hip, conv_lw.hip).
 struct Variant {
     int bm, bn, bk, s;
     int (*launch)(const ConvArgs&, int, bool, hipStream_t);
@@ -417,8 +417,13 @@ int y5_launch_conv(const y5_conv_desc& d, hipStream_t s) {
     Y5_REQUIRE(d.act == Y5_ACT_NONE || d.act == Y5_ACT_LEAKY, "conv: unknown activation %d", d.act);
     Y5_REQUIRE(d.act == Y5_ACT_NONE || (d.slope > 0.f && d.slope <= 1.f), "conv: LeakyReLU slope %g outside (0, 1]", (double)d.slope);
 
-    Y5_REQUIRE(d.variant >= 0 && d.variant <= kNumIgemm + kNumHalo + kNumWs + kNumWs3, "conv: variant %d out of range 0..%d", d.variant,
-               kNumIgemm + kNumHalo + kNumWs + kNumWs3);
+    Y5_REQUIRE(d.variant >= 0 && d.variant <= kNumIgemm + kNumHalo + kNumWs + kNumWs3 + y5_conv_lw_count(), "conv: variant %d out of range 0..%d",
+               d.variant, kNumIgemm + kNumHalo + kNumWs + kNumWs3 + y5_conv_lw_count());
+    if (d.variant > kNumIgemm + kNumHalo + kNumWs + kNumWs3) {
+        int rc = Y5_OK;
+        if (y5_try_conv_lw(d, s, d.variant - kNumIgemm - kNumHalo - kNumWs - kNumWs3, &rc)) return rc;
+        return y5_fail(Y5_EINVAL, "conv: the loader-wave variant %d does not apply to this shape", d.variant);
+    }
     if (d.variant > kNumIgemm + kNumHalo + kNumWs) {
         int rc = Y5_OK;
         if (y5_try_conv3x3_ws(d, s, d.variant - kNumIgemm - kNumHalo - kNumWs, &rc)) return rc;
@@ -482,4 +487,4 @@ int y5_launch_conv(const y5_conv_desc& d, hipStream_t s) {
     return kVariants[v].launch(a, d.ksize, direct, s);
 }
 
-int y5_conv_variant_count() { return kNumIgemm + kNumHalo + kNumWs + kNumWs3; }
+int y5_conv_variant_count() { return kNumIgemm + kNumHalo + kNumWs + kNumWs3 + y5_conv_lw_count(); }

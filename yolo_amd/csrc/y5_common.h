@@ -51,6 +51,8 @@ int y5_launch_conv(const y5_conv_desc& d, hipStream_t s);
 int y5_try_conv_halo(const y5_conv_desc& d, hipStream_t s, int force_bn, int* rc);
 int y5_try_conv_ws1x1(const y5_conv_desc& d, hipStream_t s, int which, int* rc);
 int y5_try_conv3x3_ws(const y5_conv_desc& d, hipStream_t s, int which, int* rc);
+int y5_try_conv_lw(const y5_conv_desc& d, hipStream_t s, int which, int* rc);
+int y5_conv_lw_count();
 int y5_conv_variant_count();
 // Focus gather + 3x3 convolution from the NCHW image (conv_focus.hip); d.x is the image, d.cin its 3 channels.
 int y5_launch_focus_conv(const y5_conv_desc& d, hipStream_t s, bool u8 = false);
