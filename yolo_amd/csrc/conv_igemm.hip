@@ -82,8 +82,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
     // every stage; with the XOR swizzle that slot holds K-chunk kc of the row.
     const int row0 = t / CPRW;
     const int kc = (BK == 64) ? ((t & 7) ^ ((row0 >> 1) & 7)) : ((t & 3) ^ ((row0 >> 2) & 3));
+    // Sources are byte offsets from a.x / a.w, fetched through buffer descriptors (conv_common.h: dma16_buf).
+    const i32x4 xr = make_buf(a.x, a.x_bytes), wr = make_buf(a.w, a.w_bytes);
     int hi0[A_CH], wi0[A_CH];
-    const f16* xrow[A_CH];  // DIRECT: pointer to the pixel; otherwise to pixel (b, 0, 0)
+    int xrow[A_CH];  // DIRECT: offset of the pixel; otherwise of pixel (b, 0, 0)
     bool mvalid[A_CH];
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
@@ -92,47 +94,43 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
         const unsigned mm = mvalid[i] ? (unsigned)m : 0u;
         if (DIRECT) {
             hi0[i] = wi0[i] = 0;
-            xrow[i] = a.x + (size_t)mm * a.x_ld;
+            xrow[i] = (int)(mm * (unsigned)a.x_ld * 2u);
         } else {
             const unsigned b = fdiv(mm, a.div_hw);
             const unsigned rem = mm - b * (unsigned)(a.Ho * a.Wo);
             const unsigned oy = fdiv(rem, a.div_wo), ox = rem - oy * (unsigned)a.Wo;
             hi0[i] = (int)oy * a.stride - a.pad;
             wi0[i] = (int)ox * a.stride - a.pad;
-            xrow[i] = a.x + (size_t)b * a.H * a.W * a.x_ld;
+            xrow[i] = (int)(b * (unsigned)(a.H * a.W) * (unsigned)a.x_ld * 2u);
         }
     }
-    // UT / DIRECT: running source pointer per staged row (UT: pixel of tap (0,0) -- possibly outside the image, never
-    // dereferenced then -- plus this thread's chunk; DIRECT: the pixel's current K position) and validity bits
-    const f16* acur[A_CH];
+    // UT / DIRECT: running source offset per staged row (UT: pixel of tap (0,0) -- possibly outside the image, never
+    // used then -- plus this thread's chunk; DIRECT: the pixel's current K position) and validity bits
+    int acur[A_CH];
     unsigned vmask[A_CH];
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
-        acur[i] = nullptr;
+        acur[i] = 0;
         vmask[i] = 0;
         if (UT) {
-            acur[i] = xrow[i] + ((ptrdiff_t)hi0[i] * a.W + wi0[i]) * a.x_ld + kc * 8;
+            acur[i] = xrow[i] + ((hi0[i] * a.W + wi0[i]) * a.x_ld + kc * 8) * 2;
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp) {
                 const int hi = hi0[i] + tp / 3, wi = wi0[i] + tp % 3;
                 if (mvalid[i] && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W) vmask[i] |= 1u << tp;
             }
         } else if (DIRECT) {
-            acur[i] = xrow[i] + kc * 8;
+            acur[i] = xrow[i] + kc * 16;
         }
     }
-    // The zero page's address, pinned in registers: left to itself the compiler re-derives it (a scalar load and a
-    // wait) in every K-step.
-    const void* zpage = y5_zero_page;
-    asm volatile("" : "+v"(zpage));
     int ut_tap = 0, ut_c0 = 0;  // wave-uniform: tap and first channel of the next K-step to fetch
-    ptrdiff_t ut_off = 0;       // ... and that tap's element offset from tap (0, 0), its validity bit
+    int ut_off = 0;             // ... and that tap's byte offset from tap (0, 0), its validity bit
     unsigned ut_bit = 0;
 
     const bool bload = wave < B_WAVES;  // wave-uniform
-    const f16* wptr[B_CH];
+    unsigned wptr[B_CH];
 #pragma unroll
-    for (int i = 0; i < B_CH; ++i) wptr[i] = a.w + (size_t)(n0 + (bload ? row0 : 0) + RPI * i) * a.w_ld + kc * 8;
+    for (int i = 0; i < B_CH; ++i) wptr[i] = ((unsigned)(n0 + (bload ? row0 : 0) + RPI * i) * (unsigned)a.w_ld + kc * 8) * 2u;
     const int lps = A_CH + (bload ? B_CH : 0);  // DMA instructions this wave issues per K-step
 
     // running K position of this thread's chunk
@@ -150,7 +148,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
     auto step_begin = [&]() {
         if (UT) {
             const int r = (ut_tap * 11) >> 5, q = ut_tap - 3 * r;
-            ut_off = ((ptrdiff_t)r * a.W + q) * a.x_ld + ut_c0;
+            ut_off = ((r * a.W + q) * a.x_ld + ut_c0) * 2;
             ut_bit = 1u << ut_tap;
             return;
         }
@@ -163,22 +161,22 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
     auto issue_piece = [&](int p, int stage) {
         if (p < A_CH) {
             const int i = p;
-            const void* src;
+            unsigned vo;
             if (UT) {
-                src = (vmask[i] & ut_bit) ? (const void*)(acur[i] + ut_off) : zpage;
+                vo = (vmask[i] & ut_bit) ? (unsigned)(acur[i] + ut_off) : Y5_BUF_OOB;
             } else if (DIRECT) {
-                src = (st_kvalid && mvalid[i]) ? (const void*)acur[i] : zpage;
-                acur[i] += BK;
+                vo = (st_kvalid && mvalid[i]) ? (unsigned)acur[i] : Y5_BUF_OOB;
+                acur[i] += BK * 2;
             } else {
                 const int hi = hi0[i] + st_r, wi = wi0[i] + st_q;
                 const bool ok = st_kvalid && mvalid[i] && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-                src = ok ? (const void*)(xrow[i] + (size_t)(hi * a.W + wi) * a.x_ld + cch) : zpage;
+                vo = ok ? (unsigned)(xrow[i] + ((hi * a.W + wi) * a.x_ld + cch) * 2) : Y5_BUF_OOB;
             }
-            dma16(src, lds0 + stage * STAGE_BYTES + wave * 1024 + i * PIECE);
+            dma16_buf(xr, vo, lds0 + stage * STAGE_BYTES + wave * 1024 + i * PIECE);
         } else if (bload) {
             const int i = p - A_CH;
-            dma16(wptr[i], lds0 + stage * STAGE_BYTES + BM * ROW_BYTES + wave * 1024 + i * PIECE);
-            wptr[i] += BK;
+            dma16_buf(wr, wptr[i], lds0 + stage * STAGE_BYTES + BM * ROW_BYTES + wave * 1024 + i * PIECE);
+            wptr[i] += BK * 2;
         }
     };
     auto step_end = [&]() {
@@ -440,6 +438,25 @@ int y5_launch_conv(const y5_conv_desc& d, hipStream_t s) {
         if (y5_try_conv_halo(d, s, bn, &rc)) return rc;
         if (d.variant != 0) return y5_fail(Y5_EINVAL, "conv: the halo-tile variant %d does not apply to this shape", d.variant);
     }
+    // The im2col kernel addresses x and w by 32-bit byte offsets from their first element.  A batch whose input spans
+    // 2 GiB or more is convolved in slices of whole images.
+    Y5_REQUIRE((long long)d.w_rows * d.kpad * 2 < 0x7fffffffLL, "conv: packed weights of 2 GiB or more");
+    const long long img_span = (long long)d.h * d.w_in * d.x_ld * 2;
+    const long long x_span = (((long long)d.batch * d.h * d.w_in - 1) * d.x_ld + d.cin) * 2;
+    if (x_span >= 0x7fffffffLL) {
+        Y5_REQUIRE(img_span < 0x7fffffffLL, "conv: one input image of 2 GiB or more");
+        const int per = (int)(0x7fffffffLL / img_span);
+        for (int b0 = 0; b0 < d.batch; b0 += per) {
+            y5_conv_desc part = d;
+            part.batch = d.batch - b0 < per ? d.batch - b0 : per;
+            part.x = static_cast<const f16*>(d.x) + (size_t)b0 * d.h * d.w_in * d.x_ld;
+            part.y = static_cast<f16*>(d.y) + (size_t)b0 * d.ho * d.wo * d.y_ld;
+            if (d.res) part.res = static_cast<const f16*>(d.res) + (size_t)b0 * d.ho * d.wo * d.res_ld;
+            const int rc = y5_launch_conv(part, s);
+            if (rc != Y5_OK) return rc;
+        }
+        return Y5_OK;
+    }
     ConvArgs a{};
     a.x = static_cast<const f16*>(d.x);
     a.w = static_cast<const f16*>(d.w);
@@ -459,6 +476,8 @@ int y5_launch_conv(const y5_conv_desc& d, hipStream_t s) {
     a.div_wo = make_fastdiv((unsigned)d.wo);
     a.div_cin = make_fastdiv((unsigned)d.cin);
     const bool direct = d.ksize == 1 && d.stride == 1;
+    a.x_bytes = (int)x_span;
+    a.w_bytes = (int)((long long)d.w_rows * d.kpad * 2);
 
     if (d.variant > 0) {
         // a tile reads BN whole weight rows: the packed weights (rows padded to a multiple of 128) must hold them
