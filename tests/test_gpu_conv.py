@@ -148,6 +148,8 @@ VARIANT_SHAPES = [
     (2, 64, 64, 33, 47, 3, 1),
     (2, 32, 24, 64, 64, 3, 1),
     (2, 160, 320, 12, 20, 3, 1),
+    (2, 80, 96, 20, 24, 3, 1),
+    (1, 40, 72, 17, 33, 3, 2),
 ]
 
 

@@ -40,9 +40,11 @@ struct IgemmCfg {
     static constexpr int SMEM = PRM0 + 3 * BN * 4;
 };
 
-// UT ("uniform tap", KS = 3 with Cin a multiple of BK): every chunk of a K-step belongs to the same tap, so the tap's
-// pixel offset is one wave-uniform number and a thread only keeps, per staged row, the pointer to its pixel at tap
-// (0, 0) and nine validity bits -- a DMA instruction then costs ~8 instructions of address work instead of ~20.
+// UT ("uniform tap", KS = 3): K-steps restart at every tap, so every chunk of a K-step belongs to the same tap, the tap's
+// pixel offset is one wave-uniform number and a thread only keeps, per staged row, the offset of its pixel at tap
+// (0, 0) and nine validity bits -- a DMA instruction then costs ~8 instructions of address work instead of ~20.  Where
+// Cin is not a multiple of BK the tap's last step stages zeros for the missing channels (and whatever weights follow in
+// the row: their products vanish).
 template <int BM, int BN, int WM, int WN, int KS, int S, int BK, bool DIRECT, bool UT = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs a) {
     static_assert(!UT || (KS == 3 && !DIRECT), "uniform-tap addressing is for 3x3 convolutions");
@@ -124,8 +126,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
         }
     }
     int ut_tap = 0, ut_c0 = 0;  // wave-uniform: tap and first channel of the next K-step to fetch
-    int ut_off = 0;             // ... and that tap's byte offset from tap (0, 0), its validity bit
-    unsigned ut_bit = 0;
+    int ut_off = 0;             // ... and that tap's byte offset from tap (0, 0), its validity bit,
+    unsigned ut_bit = 0;        // the step's byte offset in a weight row
+    int ut_w = 0;
 
     const bool bload = wave < B_WAVES;  // wave-uniform
     unsigned wptr[B_CH];
@@ -150,6 +153,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
             const int r = (ut_tap * 11) >> 5, q = ut_tap - 3 * r;
             ut_off = ((r * a.W + q) * a.x_ld + ut_c0) * 2;
             ut_bit = 1u << ut_tap;
+            ut_w = (ut_tap * a.Cin + ut_c0) * 2;
             return;
         }
         if (KS > 1) {
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
             const int i = p;
             unsigned vo;
             if (UT) {
-                vo = (vmask[i] & ut_bit) ? (unsigned)(acur[i] + ut_off) : Y5_BUF_OOB;
+                vo = ((vmask[i] & ut_bit) && ut_c0 + kc * 8 < a.Cin) ? (unsigned)(acur[i] + ut_off) : Y5_BUF_OOB;
             } else if (DIRECT) {
                 vo = (st_kvalid && mvalid[i]) ? (unsigned)acur[i] : Y5_BUF_OOB;
                 acur[i] += BK * 2;
@@ -175,8 +179,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
             dma16_buf(xr, vo, lds0 + stage * STAGE_BYTES + wave * 1024 + i * PIECE);
         } else if (bload) {
             const int i = p - A_CH;
-            dma16_buf(wr, wptr[i], lds0 + stage * STAGE_BYTES + BM * ROW_BYTES + wave * 1024 + i * PIECE);
-            wptr[i] += BK * 2;
+            dma16_buf(wr, UT ? wptr[i] + (unsigned)ut_w : wptr[i], lds0 + stage * STAGE_BYTES + BM * ROW_BYTES + wave * 1024 + i * PIECE);
+            if (!UT) wptr[i] += BK * 2;
         }
     };
     auto step_end = [&]() {
@@ -344,7 +348,9 @@ int launch_tile(const ConvArgs& a0, int ksize, bool direct, hipStream_t s) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
         attr_set.fetch_or(attr_set_bit);
     }
-    if (ksize == 3 && a.Cin % BK == 0 && !getenv("Y5_NO_UT"))
+    const bool ut = ksize == 3 && !getenv("Y5_NO_UT");
+    if (ut) a.nk = 9 * ((a.Cin + BK - 1) / BK);
+    if (ut)
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 3, S, BK, false, true>), grid, block, Cfg::SMEM, s, a);
     else if (ksize == 3)
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 3, S, BK, false>), grid, block, Cfg::SMEM, s, a);

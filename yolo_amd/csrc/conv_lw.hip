@@ -5,8 +5,8 @@
 // at a time, ~150 cycles apart per wave under load) for about as long as its MFMAs take, and the two never overlap
 // within a wave; here the K-step costs the longer of the two instead of their sum.
 //
-// Covers the two addressing modes that need no per-chunk coordinate decode: 3x3 (any stride) with Cin a multiple of
-// the K-step (every K-step lies in one tap), and 1x1 stride 1.  Everything else stays with conv_igemm.hip.
+// Covers the two addressing modes that need no per-chunk coordinate decode: 3x3 (any stride; K-steps restart at every
+// tap, so a step lies in one tap) and 1x1 stride 1.  Everything else stays with conv_igemm.hip.
 #include "y5_common.h"
 
 namespace {
@@ -40,11 +40,10 @@ struct LwCfg {
     static constexpr int SMEM = PRM0 + 3 * BN * 4;
 };
 
-// DIRECT: 1x1 stride 1 (output pixel m reads input pixel m); otherwise 3x3 with Cin % BK == 0.
-// BUF: the loaders use buffer_load ... lds (one scalar descriptor per tensor, a 32-bit byte offset per lane, zeros
-// from the hardware's range check for chunks outside the image) instead of global_load_lds with 64-bit lane addresses
-// and the zero page.
-template <int BM, int BN, int WM, int WN, int NL, int S, int BK, bool DIRECT, bool BUF>
+// DIRECT: 1x1 stride 1 (output pixel m reads input pixel m); otherwise 3x3.
+// The loaders use buffer_load ... lds: one scalar descriptor per tensor, a 32-bit byte offset per lane, zeros from the
+// hardware's range check for chunks outside the image or past a tap's channels.
+template <int BM, int BN, int WM, int WN, int NL, int S, int BK, bool DIRECT>
 __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_lw_kernel(const ConvArgs a) {
     typedef LwCfg<BM, BN, WM, WN, NL, S, BK> Cfg;
     constexpr int NWC = WM * WN, NT = Cfg::NT;
@@ -77,173 +76,84 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_lw_kernel(const Conv
     if (wave >= NWC) {
         // ------------------------------------------------------------------ loader waves
         const int lw = wave - NWC;
-        if constexpr (BUF) {
-            // Byte offsets from the tensor's first element; OOB (>= num_records under any reading of the range check,
-            // and no 32-bit wrap with the offsets added to it) makes the hardware return zeros.
-            constexpr unsigned OOB = 0x80000000u;
-            const BufRsrc xr = make_rsrc(a.x, a.x_bytes), wr = make_rsrc(a.w, a.w_bytes);
-            int abase[A_CH];       // byte offset of this lane's chunk at tap (0, 0) / K position 0 (may be negative when masked)
-            unsigned vmask[A_CH];  // 3x3: validity bit per tap; 1x1: pixel in range
-            int kc8[A_CH];
+        // Byte offsets from the tensor's first element; OOB (>= num_records under any reading of the range check,
+        // and no 32-bit wrap with the offsets added to it) makes the hardware return zeros.
+        constexpr unsigned OOB = 0x80000000u;
+        const BufRsrc xr = make_rsrc(a.x, a.x_bytes), wr = make_rsrc(a.w, a.w_bytes);
+        int abase[A_CH];       // byte offset of this lane's chunk at tap (0, 0) / K position 0 (may be negative when masked)
+        unsigned vmask[A_CH];  // 3x3: validity bit per tap; 1x1: pixel in range
+        int kc8[A_CH];
 #pragma unroll
-            for (int i = 0; i < A_CH; ++i) {
-                const int row = (lw + NL * i) * RPW + lane / CPRW;
-                const int kc = (lane % CPRW) ^ ((BK == 64) ? ((row >> 1) & 7) : ((row >> 2) & 3));
-                kc8[i] = kc * 8;
-                const int m = m0 + row;
-                const bool mvalid = m < a.M;
-                const unsigned mm = mvalid ? (unsigned)m : 0u;
-                vmask[i] = 0;
-                if (DIRECT) {
-                    abase[i] = (int)((mm * (unsigned)a.x_ld + kc * 8) * 2u);
-                    vmask[i] = mvalid ? 1u : 0u;
-                } else {
-                    const unsigned b = fdiv(mm, a.div_hw);
-                    const unsigned rem = mm - b * (unsigned)(a.Ho * a.Wo);
-                    const unsigned oy = fdiv(rem, a.div_wo), ox = rem - oy * (unsigned)a.Wo;
-                    const int hi0 = (int)oy * a.stride - a.pad, wi0 = (int)ox * a.stride - a.pad;
-                    abase[i] = (((int)b * a.H + hi0) * a.W + wi0) * a.x_ld * 2 + kc * 16;
+        for (int i = 0; i < A_CH; ++i) {
+            const int row = (lw + NL * i) * RPW + lane / CPRW;
+            const int kc = (lane % CPRW) ^ ((BK == 64) ? ((row >> 1) & 7) : ((row >> 2) & 3));
+            kc8[i] = kc * 8;
+            const int m = m0 + row;
+            const bool mvalid = m < a.M;
+            const unsigned mm = mvalid ? (unsigned)m : 0u;
+            vmask[i] = 0;
+            if (DIRECT) {
+                abase[i] = (int)((mm * (unsigned)a.x_ld + kc * 8) * 2u);
+                vmask[i] = mvalid ? 1u : 0u;
+            } else {
+                const unsigned b = fdiv(mm, a.div_hw);
+                const unsigned rem = mm - b * (unsigned)(a.Ho * a.Wo);
+                const unsigned oy = fdiv(rem, a.div_wo), ox = rem - oy * (unsigned)a.Wo;
+                const int hi0 = (int)oy * a.stride - a.pad, wi0 = (int)ox * a.stride - a.pad;
+                abase[i] = (((int)b * a.H + hi0) * a.W + wi0) * a.x_ld * 2 + kc * 16;
 #pragma unroll
-                    for (int tp = 0; tp < 9; ++tp) {
-                        const int hi = hi0 + tp / 3, wi = wi0 + tp % 3;
-                        if (mvalid && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W) vmask[i] |= 1u << tp;
-                    }
+                for (int tp = 0; tp < 9; ++tp) {
+                    const int hi = hi0 + tp / 3, wi = wi0 + tp % 3;
+                    if (mvalid && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W) vmask[i] |= 1u << tp;
                 }
             }
-            unsigned wbase[B_CH];
-#pragma unroll
-            for (int i = 0; i < B_CH; ++i) {
-                const int row = (lw + NL * i) * RPW + lane / CPRW;
-                const int kc = (lane % CPRW) ^ ((BK == 64) ? ((row >> 1) & 7) : ((row >> 2) & 3));
-                wbase[i] = ((unsigned)(n0 + row) * (unsigned)a.w_ld + kc * 8) * 2u;
-            }
-            int tap = 0, c0 = 0, kbase = 0;
-            auto issue = [&](int stage) {
-                int off = kbase * 2;
-                unsigned bit = 1u;
-                if (!DIRECT) {
-                    const int r = (tap * 11) >> 5, q = tap - 3 * r;
-                    off = ((r * a.W + q) * a.x_ld + c0) * 2;
-                    bit = 1u << tap;
-                }
-                unsigned char* base = smem + stage * STAGE_BYTES + lw * 1024;
-#pragma unroll
-                for (int i = 0; i < A_CH; ++i) {
-                    const bool ok = DIRECT ? (vmask[i] && kbase + kc8[i] < a.K) : ((vmask[i] & bit) != 0);
-                    const unsigned vo = ok ? (unsigned)(abase[i] + off) : OOB;
-                    buf_dma16(xr, (lds_ptr)(base + i * (NL * 1024)), vo, 0);
-                }
-#pragma unroll
-                for (int i = 0; i < B_CH; ++i)
-                    buf_dma16(wr, (lds_ptr)(base + BM * ROW_BYTES + i * (NL * 1024)), wbase[i], kbase * 2);
-                kbase += BK;
-                if (!DIRECT) {
-                    c0 += BK;
-                    if (c0 >= a.Cin) {
-                        c0 = 0;
-                        ++tap;
-                    }
-                }
-            };
-#pragma unroll
-            for (int s = 0; s < S - 1; ++s)
-                if (s < nk) issue(s);
-            for (int kt = 0; kt < nk; ++kt) {
-                int ahead = nk - 1 - kt;
-                if (ahead > S - 2) ahead = S - 2;
-                wait_vm_and_barrier(ahead * LPS);
-                if (kt + S - 1 < nk) issue((kt + S - 1) % S);
-            }
-            wait_vm_and_barrier(0);
-        } else {
-            const void* zpage = y5_zero_page;
-            asm volatile("" : "+v"(zpage));
-            const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-            // piece i of this wave = rows [(lw + NL*i) * RPW, +RPW) of the tile; lane -> (row, 16-byte slot); with the
-            // XOR swizzle the slot holds K-chunk kc of the row
-            const f16* acur[A_CH];
-            unsigned vmask[A_CH];
-            int kc8[A_CH];
-#pragma unroll
-            for (int i = 0; i < A_CH; ++i) {
-                const int row = (lw + NL * i) * RPW + lane / CPRW;
-                const int kc = (lane % CPRW) ^ ((BK == 64) ? ((row >> 1) & 7) : ((row >> 2) & 3));
-                kc8[i] = kc * 8;
-                const int m = m0 + row;
-                const bool mvalid = m < a.M;
-                const unsigned mm = mvalid ? (unsigned)m : 0u;
-                vmask[i] = 0;
-                if (DIRECT) {
-                    acur[i] = a.x + (size_t)mm * a.x_ld + kc * 8;
-                    vmask[i] = mvalid ? 1u : 0u;
-                } else {
-                    const unsigned b = fdiv(mm, a.div_hw);
-                    const unsigned rem = mm - b * (unsigned)(a.Ho * a.Wo);
-                    const unsigned oy = fdiv(rem, a.div_wo), ox = rem - oy * (unsigned)a.Wo;
-                    const int hi0 = (int)oy * a.stride - a.pad, wi0 = (int)ox * a.stride - a.pad;
-                    // pixel of tap (0, 0): possibly outside the image, never dereferenced then
-                    acur[i] = a.x + ((ptrdiff_t)b * a.H * a.W + (ptrdiff_t)hi0 * a.W + wi0) * a.x_ld + kc * 8;
-#pragma unroll
-                    for (int tp = 0; tp < 9; ++tp) {
-                        const int hi = hi0 + tp / 3, wi = wi0 + tp % 3;
-                        if (mvalid && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W) vmask[i] |= 1u << tp;
-                    }
-                }
-            }
-            const f16* wptr[B_CH];
-#pragma unroll
-            for (int i = 0; i < B_CH; ++i) {
-                const int row = (lw + NL * i) * RPW + lane / CPRW;
-                const int kc = (lane % CPRW) ^ ((BK == 64) ? ((row >> 1) & 7) : ((row >> 2) & 3));
-                wptr[i] = a.w + (size_t)(n0 + row) * a.w_ld + kc * 8;
-            }
-            int tap = 0, c0 = 0, kbase = 0;  // wave-uniform position of the next K-step to fetch
-            auto issue = [&](int stage) {
-                ptrdiff_t off = 0;
-                unsigned bit = 1u;
-                if (!DIRECT) {
-                    const int r = (tap * 11) >> 5, q = tap - 3 * r;  // tap / 3, tap % 3
-                    off = ((ptrdiff_t)r * a.W + q) * a.x_ld + c0;
-                    bit = 1u << tap;
-                }
-                const unsigned base = lds0 + stage * STAGE_BYTES + lw * 1024;
-#pragma unroll
-                for (int i = 0; i < A_CH; ++i) {
-                    const void* src;
-                    if (DIRECT) {
-                        src = (vmask[i] && kbase + kc8[i] < a.K) ? (const void*)acur[i] : zpage;
-                        acur[i] += BK;
-                    } else {
-                        src = (vmask[i] & bit) ? (const void*)(acur[i] + off) : zpage;
-                    }
-                    dma16(src, base + i * (NL * 1024));
-                }
-#pragma unroll
-                for (int i = 0; i < B_CH; ++i) {
-                    dma16(wptr[i], base + BM * ROW_BYTES + i * (NL * 1024));
-                    wptr[i] += BK;
-                }
-                kbase += BK;
-                if (!DIRECT) {
-                    c0 += BK;
-                    if (c0 >= a.Cin) {
-                        c0 = 0;
-                        ++tap;
-                    }
-                }
-            };
-#pragma unroll
-            for (int s = 0; s < S - 1; ++s)
-                if (s < nk) issue(s);
-            for (int kt = 0; kt < nk; ++kt) {
-                // K-steps kt+1 .. min(kt+S-2, nk-1) may stay in flight; step kt must have landed before the consumers pass
-                int ahead = nk - 1 - kt;
-                if (ahead > S - 2) ahead = S - 2;
-                wait_vm_and_barrier(ahead * LPS);
-                if (kt + S - 1 < nk) issue((kt + S - 1) % S);  // the buffer of step kt-1: every consumer is past its reads
-            }
-            wait_vm_and_barrier(0);
         }
+        unsigned wbase[B_CH];
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) {
+            const int row = (lw + NL * i) * RPW + lane / CPRW;
+            const int kc = (lane % CPRW) ^ ((BK == 64) ? ((row >> 1) & 7) : ((row >> 2) & 3));
+            wbase[i] = ((unsigned)(n0 + row) * (unsigned)a.w_ld + kc * 8) * 2u;
+        }
+        int tap = 0, c0 = 0, kbase = 0;
+        auto issue = [&](int stage) {
+            int off = kbase * 2;
+            unsigned bit = 1u;
+            if (!DIRECT) {
+                const int r = (tap * 11) >> 5, q = tap - 3 * r;
+                off = ((r * a.W + q) * a.x_ld + c0) * 2;
+                bit = 1u << tap;
+            }
+            const int koff = (DIRECT ? kbase : tap * a.Cin + c0) * 2;  // this K-step's byte offset in a weight row
+            unsigned char* base = smem + stage * STAGE_BYTES + lw * 1024;
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) {
+                const bool ok = DIRECT ? (vmask[i] && kbase + kc8[i] < a.K) : ((vmask[i] & bit) != 0 && c0 + kc8[i] < a.Cin);
+                const unsigned vo = ok ? (unsigned)(abase[i] + off) : OOB;
+                buf_dma16(xr, (lds_ptr)(base + i * (NL * 1024)), vo, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < B_CH; ++i)
+                buf_dma16(wr, (lds_ptr)(base + BM * ROW_BYTES + i * (NL * 1024)), wbase[i] + (unsigned)koff, 0);
+            kbase += BK;
+            if (!DIRECT) {
+                c0 += BK;
+                if (c0 >= a.Cin) {
+                    c0 = 0;
+                    ++tap;
+                }
+            }
+        };
+#pragma unroll
+        for (int s = 0; s < S - 1; ++s)
+            if (s < nk) issue(s);
+        for (int kt = 0; kt < nk; ++kt) {
+            int ahead = nk - 1 - kt;
+            if (ahead > S - 2) ahead = S - 2;
+            wait_vm_and_barrier(ahead * LPS);
+            if (kt + S - 1 < nk) issue((kt + S - 1) % S);
+        }
+        wait_vm_and_barrier(0);
     } else {
         // ------------------------------------------------------------------ consumer waves
         const int wm = wave % WM, wn = wave / WM;
@@ -301,15 +211,15 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_lw_kernel(const Conv
     // ---- all waves: 16-byte stores of the finished tile (+ residual)
     constexpr int CPR = BN / 8;    // 16-byte chunks per tile row
     constexpr int RPP = NT / CPR;  // rows per pass
-    static_assert(NT % CPR == 0 && BM % RPP == 0, "the store loop covers the tile in whole passes");
+    static_assert(NT % CPR == 0, "whole rows per pass");
     const int cc = t % CPR, rr = t / CPR;
     const int n = n0 + cc * 8;
     if (n < a.Cout) {
 #pragma unroll
-        for (int p = 0; p < BM / RPP; ++p) {
+        for (int p = 0; p < (BM + RPP - 1) / RPP; ++p) {
             const int row = rr + p * RPP;
             const int m = m0 + row;
-            if (m < a.M) {
+            if (row < BM && m < a.M) {
                 f16x8 v = *reinterpret_cast<const f16x8*>(smem + row * EP + cc * 16);
                 if (a.res) v += *reinterpret_cast<const f16x8*>(a.res + (size_t)m * a.res_ld + n);
                 *reinterpret_cast<f16x8*>(a.y + (size_t)m * a.y_ld + n) = v;
@@ -318,51 +228,49 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_lw_kernel(const Conv
     }
 }
 
-template <int BM, int BN, int WM, int WN, int NL, int S, int BK, bool BUF>
+template <int BM, int BN, int WM, int WN, int NL, int S, int BK>
 int launch_lw(const ConvArgs& a0, bool direct, hipStream_t s) {
     typedef LwCfg<BM, BN, WM, WN, NL, S, BK> Cfg;
     ConvArgs a = a0;
     const long long tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.Cout + BN - 1) / BN;
-    a.nk = (a.K + BK - 1) / BK;  // the weight rows are zero-padded to a multiple of 64 >= K
+    // 1x1: K-steps over the weight row, zero-padded to a multiple of 64 >= K.  3x3: every tap starts a fresh K-step, so a
+    // step never mixes taps; where Cin is not a multiple of BK the tap's last step stages zeros for the missing channels
+    // (and whatever weights follow: their products vanish).
+    a.nk = direct ? (a.K + BK - 1) / BK : 9 * ((a.Cin + BK - 1) / BK);
     const long long total = tiles_m * a.tiles_n;
     if (total <= 0 || total > 0x7fffffffLL) return y5_fail(Y5_EINVAL, "conv: tile count %lld out of range", total);
     a.tiles_total = (int)total;
     static std::atomic<unsigned long long> attr_set{0};  // one bit per device: the attribute is per function and device
     const unsigned long long bit = 1ull << y5_current_device();
     if (!(attr_set.load() & bit)) {
-        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lw_kernel<BM, BN, WM, WN, NL, S, BK, false, BUF>),
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lw_kernel<BM, BN, WM, WN, NL, S, BK, false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
-        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lw_kernel<BM, BN, WM, WN, NL, S, BK, true, BUF>),
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lw_kernel<BM, BN, WM, WN, NL, S, BK, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
         attr_set.fetch_or(bit);
     }
     const dim3 grid((unsigned)total), block(Cfg::NT);
     if (direct)
-        hipLaunchKernelGGL((conv_lw_kernel<BM, BN, WM, WN, NL, S, BK, true, BUF>), grid, block, Cfg::SMEM, s, a);
+        hipLaunchKernelGGL((conv_lw_kernel<BM, BN, WM, WN, NL, S, BK, true>), grid, block, Cfg::SMEM, s, a);
     else
-        hipLaunchKernelGGL((conv_lw_kernel<BM, BN, WM, WN, NL, S, BK, false, BUF>), grid, block, Cfg::SMEM, s, a);
+        hipLaunchKernelGGL((conv_lw_kernel<BM, BN, WM, WN, NL, S, BK, false>), grid, block, Cfg::SMEM, s, a);
     Y5_LAUNCH_CHECK("conv_lw_kernel");
     return Y5_OK;
 }
 
 struct LwVariant {
     int bn, bk;
-    bool buf;
     int (*launch)(const ConvArgs&, bool, hipStream_t);
 };
-#define Y5_LW(BM, BN, WM, WN, NL, S, BK) {BN, BK, false, &launch_lw<BM, BN, WM, WN, NL, S, BK, false>}
-#define Y5_LB(BM, BN, WM, WN, NL, S, BK) {BN, BK, true, &launch_lw<BM, BN, WM, WN, NL, S, BK, true>}
+#define Y5_LW(BM, BN, WM, WN, NL, S, BK) {BN, BK, &launch_lw<BM, BN, WM, WN, NL, S, BK>}
 const LwVariant kLw[] = {
     Y5_LW(256, 128, 4, 2, 8, 2, 64), Y5_LW(256, 128, 4, 2, 8, 3, 64), Y5_LW(256, 128, 4, 2, 8, 3, 32),
     Y5_LW(128, 128, 2, 2, 4, 2, 64), Y5_LW(128, 128, 2, 2, 4, 3, 32), Y5_LW(128, 128, 2, 4, 8, 3, 64),
-    Y5_LW(256, 64, 4, 2, 8, 3, 64),  Y5_LW(128, 64, 2, 2, 4, 3, 64),
-    Y5_LB(256, 128, 4, 2, 8, 2, 64), Y5_LB(256, 128, 4, 2, 8, 3, 64), Y5_LB(256, 128, 4, 2, 8, 3, 32),
-    Y5_LB(128, 128, 2, 2, 4, 2, 64), Y5_LB(128, 128, 2, 2, 4, 3, 32), Y5_LB(128, 128, 2, 4, 8, 3, 64),
-    Y5_LB(256, 64, 4, 2, 8, 3, 64),  Y5_LB(128, 64, 2, 2, 4, 3, 64),
+    Y5_LW(256, 64, 4, 2, 8, 3, 64),  Y5_LW(128, 64, 2, 2, 4, 3, 64),  Y5_LW(64, 64, 2, 2, 4, 3, 64),
+    Y5_LW(64, 128, 2, 2, 4, 3, 64),  Y5_LW(256, 256, 2, 4, 4, 2, 64), Y5_LW(256, 256, 2, 4, 4, 3, 32),
 };
 #undef Y5_LW
-#undef Y5_LB
 
 }  // namespace
 
@@ -373,7 +281,7 @@ int y5_try_conv_lw(const y5_conv_desc& d, hipStream_t s, int which, int* rc) {
     if (which < 1 || which > y5_conv_lw_count()) return 0;
     const LwVariant& v = kLw[which - 1];
     const bool direct = d.ksize == 1 && d.stride == 1;
-    if (!direct && !(d.ksize == 3 && d.cin % v.bk == 0)) return 0;
+    if (!direct && d.ksize != 3) return 0;
     if ((long long)((d.cout + v.bn - 1) / v.bn) * v.bn > d.w_rows) return 0;
     ConvArgs a{};
     a.x = static_cast<const f16*>(d.x);
@@ -394,7 +302,7 @@ int y5_try_conv_lw(const y5_conv_desc& d, hipStream_t s, int which, int* rc) {
     a.div_cin = make_fastdiv((unsigned)d.cin);
     // spans the loaders may touch, for the buffer descriptors (32-bit offsets, sentinel 2^31 for zeros)
     const long long xb = (((long long)d.batch * d.h * d.w_in - 1) * d.x_ld + d.cin) * 2, wb = (long long)d.w_rows * d.kpad * 2;
-    if (v.buf && (xb >= 0x7fffffffLL || wb >= 0x7fffffffLL)) return 0;
+    if (xb >= 0x7fffffffLL || wb >= 0x7fffffffLL) return 0;
     a.x_bytes = (int)xb;
     a.w_bytes = (int)wb;
     *rc = v.launch(a, direct, s);
