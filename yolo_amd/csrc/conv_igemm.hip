@@ -348,8 +348,11 @@ int launch_tile(const ConvArgs& a0, int ksize, bool direct, hipStream_t s) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
         attr_set.fetch_or(attr_set_bit);
     }
-    const bool ut = ksize == 3 && !getenv("Y5_NO_UT");
-    if (ut) a.nk = 9 * ((a.Cin + BK - 1) / BK);
+    // uniform-tap addressing whenever restarting the K-steps at every tap costs no extra step over walking K = 9 Cin
+    // contiguously (always when Cin is a multiple of BK)
+    const int nk_ut = 9 * ((a.Cin + BK - 1) / BK);
+    const bool ut = ksize == 3 && nk_ut <= a.nk && !getenv("Y5_NO_UT");
+    if (ut) a.nk = nk_ut;
     if (ut)
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 3, S, BK, false, true>), grid, block, Cfg::SMEM, s, a);
     else if (ksize == 3)
