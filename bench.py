@@ -160,7 +160,7 @@ def main():
             with open(tpath) as f:
                 traffic = json.load(f).get('conv_total')  # rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of the same launches
         top = sorted(conv, key=lambda a: -a['ms'])[:6]
-        roofline = {'kernel': 'convolution kernels (conv_igemm / conv_ws1x1 / conv_halo3x3 / focus_conv): all %d launches of one forward'
+        roofline = {'kernel': 'convolution kernels (conv_igemm / conv_lw / conv_ws1x1 / conv3x3_ws / focus_conv): all %d launches of one forward'
                               % len(conv),
                     'bound': 'hbm' if hbm_bound else 'mfma',
                     'achieved': round(gbs if hbm_bound else tflops, 2), 'peak': PEAK_HBM_GBS if hbm_bound else PEAK_MFMA_TFLOPS,

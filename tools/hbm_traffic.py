@@ -25,7 +25,7 @@ def one_step(root, counter):
 
 
 def family(name):
-    for key in ('focus_conv', 'conv_igemm', 'conv_halo', 'conv_ws1x1', 'conv3x3_ws', 'detect_decode', 'nms_', 'maxpool', 'upsample', 'copy_channels'):
+    for key in ('focus_conv', 'conv_lw', 'conv_igemm', 'conv_halo', 'conv_ws1x1', 'conv3x3_ws', 'detect_decode', 'nms_', 'maxpool', 'upsample', 'copy_channels'):
         if key in name:
             return key
     return 'other'
