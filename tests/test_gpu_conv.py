@@ -270,3 +270,38 @@ def test_conv_into_channel_slice_leaves_neighbours_alone(dev):
     assert bool((buf[..., :64] == 7).all()) and bool((buf[..., 96:] == 7).all())
     ref = (x.float().view(-1, 64) @ w[:32].float().t()).half().view(2, 20, 20, 32)
     close(buf[..., 64:96], ref)
+
+
+def test_input_of_two_gib_or_more_is_convolved_in_image_slices(dev):
+    """The im2col kernel addresses its input by 32-bit byte offsets; y5_conv_f16 splits a batch whose input spans 2 GiB
+    or more into runs of whole images.  Every image of such a batch must equal the same image convolved alone."""
+    lib = _lib.lib()
+    B, H, W, Ci, Co = 9, 1024, 1024, 128, 8      # 9 x 256 MiB of input: slices of 7 + 2 images
+    g = torch.Generator().manual_seed(3)
+    x = torch.empty(B, H, W, Ci, dtype=torch.float16, device=dev)
+    x[0] = torch.randn(H, W, Ci, generator=g).half().to(dev)
+    for b in range(1, B):                         # image b = image 0 times (b + 1): distinct images, cheap to make
+        x[b] = x[0] * (b + 1)
+    w = (torch.randn(Co, Ci, generator=g) / Ci ** 0.5).half().to(dev)
+    wp = torch.zeros(256, 128, dtype=torch.float16, device=dev)
+    wp[:Co] = w
+
+    def conv(xb):
+        y = torch.full((xb.shape[0], H, W, Co), float('nan'), dtype=torch.float16, device=dev)
+        d = _lib.ConvDesc()
+        d.x, d.w, d.y = xb.data_ptr(), wp.data_ptr(), y.data_ptr()
+        d.batch, d.h, d.w_in, d.cin, d.x_ld = xb.shape[0], H, W, Ci, Ci
+        d.ho, d.wo, d.cout, d.y_ld = H, W, Co, Co
+        d.ksize, d.stride, d.pad, d.kpad, d.w_rows = 1, 1, 0, 128, 256
+        d.act, d.slope = _lib.ACT_NONE, 0.0
+        _lib.check(lib.y5_conv_f16(C.byref(d), _lib.current_stream()))
+        torch.cuda.synchronize()
+        return y
+
+    assert x.numel() * 2 >= 2 ** 31
+    whole = conv(x)
+    assert not bool(torch.isnan(whole).any())
+    for b in (0, 6, 7, 8):                        # both sides of the slice boundary
+        assert torch.equal(whole[b], conv(x[b:b + 1])[0])
+    ref = (x[8, :64, :64].float() @ w.float().t()).half()
+    close(whole[8, :64, :64].permute(2, 0, 1)[None], ref.permute(2, 0, 1)[None])
