@@ -76,15 +76,16 @@ typedef struct y5_conv_desc {
     int32_t ho, wo, cout, y_ld, res_ld;
     int32_t ksize, stride, pad; /* ksize in {1,3}; stride in {1,2}; pad = ksize/2                  */
     int32_t kpad;               /* >= ksize*ksize*cin, multiple of 64                               */
-    int32_t w_rows;             /* >= cout, multiple of 128                                         */
+    int32_t w_rows;             /* >= cout, multiple of 128 (256 for the variants with 256-channel tiles) */
     int32_t act;                /* Y5_ACT_*                                                         */
     float slope;                /* LeakyReLU negative slope (0.1 in the reference)                  */
     int32_t variant;            /* 0 = tile configuration chosen by rule; 1..y5_conv_num_variants() = explicit   */
 } y5_conv_desc;
 
 int y5_conv_f16(const y5_conv_desc* d, y5_stream_t stream);
-/* Number of compiled tile configurations of the convolution kernel (for autotuning the `variant` field: time
- * each id on the real shape and keep the fastest; an id that does not apply to the shape returns Y5_EINVAL). */
+/* Number of compiled kernel variants (tile configurations of the im2col kernel, then the halo, weight-stationary and
+ * loader-wave kernel families), for autotuning the `variant` field: time each id on the real shape and keep the
+ * fastest; an id that does not apply to the shape returns Y5_EINVAL. */
 int y5_conv_num_variants(void);
 
 /* Focus followed by its 3x3 stride-1 pad-1 convolution, straight from the NCHW image, without materialising the

@@ -1,9 +1,10 @@
 // Implicit-GEMM convolution with dedicated loader waves ("lw"): same GEMM view, LDS ring image, swizzle, MFMA
 // fragment layout and epilogue as conv_igemm.hip, but the workgroup is split by role.  WM x WN consumer waves only
-// read fragments and issue MFMAs; NL loader waves only compute source addresses and issue the global->LDS DMAs.
-// In the one-role kernel a wave is stopped in its DMA issue (the memory pipeline takes one 1 KB wave-instruction
-// at a time, ~150 cycles apart per wave under load) for about as long as its MFMAs take, and the two never overlap
-// within a wave; here the K-step costs the longer of the two instead of their sum.
+// read fragments and issue MFMAs; NL loader waves only compute source offsets and issue the global->LDS DMAs
+// (buffer_load ... lds).  Measured on gfx950 (tools/exp/lds_dma_rate.hip): a wave's DMA issue and its own MFMAs never
+// overlap, and with global_load_lds not even those of its SIMD neighbour do, so a one-role K-step costs staging time
+// plus MFMA time; buffer-descriptor DMAs issued by other waves do proceed beside the MFMAs (1550 instead of 2030-2430
+// cycles for a 48 KB step next to 16 MFMAs per wave).
 //
 // Covers the two addressing modes that need no per-chunk coordinate decode: 3x3 (any stride; K-steps restart at every
 // tap, so a step lies in one tap) and 1x1 stride 1.  Everything else stays with conv_igemm.hip.
