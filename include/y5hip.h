@@ -164,6 +164,17 @@ int y5_detect_decode_f16(const y5_decode_desc* d, y5_stream_t stream);
 #define Y5_MAX_LEVELS 4
 int y5_detect_decode_multi_f16(const y5_decode_desc* levels, int n_levels, y5_stream_t stream);
 
+/* One Detect level in one kernel: the level's 1x1 convolution self.m[i] (bias, no activation) with the decode above as
+ * its epilogue.  Replaces: Detect.forward  models/yolo.py:32-46 for level i (conv, view/permute/contiguous, sigmoid, box
+ * decode, view into z) without the NHWC head tensor in between.  conv: ksize 1, stride 1, cout = na*no padded to a
+ * multiple of 8 (<= 256), weights packed to 256 rows, y unused; d: as for y5_detect_decode_f16 with head unused.  Needs
+ * the 16-byte store alignment of the decode kernel's fast path (ny*nx*no, z_rows_total*no and z_row0*no multiples of 8),
+ * else Y5_EINVAL: use the two separate calls then.  variant: 0 or 1..y5_detect_num_variants() (tile configurations, for
+ * autotuning like y5_conv_desc.variant).  Same values as the two-kernel path up to the fp32 summation order of the
+ * convolution. */
+int y5_detect_f16(const y5_conv_desc* conv, const y5_decode_desc* d, int variant, y5_stream_t stream);
+int y5_detect_num_variants(void);
+
 /* y[i] = fp16(sigmoid(x[i])) for n fp16 values, the elementwise op of Detect.forward (x[i].sigmoid(), models/yolo.py:41)
  * exactly as the decode kernel evaluates it.  libm = 0: the kernel's exp2/reciprocal form; libm = 1: 1/(1+expf(-x)) with
  * IEEE division.  Both must agree on all 65536 inputs; the entry point exists so that this can be tested. */
@@ -262,6 +273,7 @@ int y5_plan_add_upsample2x(y5_plan* p, const void* x, int x_ld, void* y, int y_l
 int y5_plan_add_copy_channels(y5_plan* p, const void* x, int x_ld, void* y, int y_ld, int64_t pixels, int c);
 int y5_plan_add_decode(y5_plan* p, const y5_decode_desc* d);
 int y5_plan_add_decode_multi(y5_plan* p, const y5_decode_desc* levels, int n_levels);
+int y5_plan_add_detect(y5_plan* p, const y5_conv_desc* conv, const y5_decode_desc* d, int variant);
 /* Mark the op recorded last.  Y5_PLAN_SIDE: y5_plan_run launches it on a second stream owned by the plan, ordered
  * after everything issued before it on the caller's stream -- for an op whose result is needed only much later (the
  * Detect convs of the finer pyramid levels, which can run beside the rest of the head).  Y5_PLAN_JOIN: the caller's
@@ -288,6 +300,7 @@ int y5_plan_profile(y5_plan* p, void* const* ext, int n_ext, y5_stream_t stream,
 #define Y5_OP_DECODE_MULTI 9
 #define Y5_OP_FOCUS_CONV_U8 10
 #define Y5_OP_NORMALIZE_U8 11
+#define Y5_OP_DETECT 12
 int y5_plan_op_info(const y5_plan* p, int i, int* kind, double* flops, double* bytes);
 
 #ifdef __cplusplus

@@ -360,3 +360,66 @@ def test_nms_is_idempotent_on_its_own_output(dev):
     d = det[0, :n]
     keep = hip_nms.nms(d[:, :4].contiguous(), d[:, 4].contiguous(), 0.5, max_keep=300)
     assert keep.tolist() == list(range(n))
+
+
+@pytest.mark.parametrize('shape', [(2, 128, 16, 24), (3, 256, 20, 20), (1, 72, 7, 9), (2, 72, 8, 8)], ids=lambda s: 'x'.join(map(str, s)))
+def test_detect_level_in_one_kernel_equals_conv_then_decode(dev, shape):
+    """y5_detect_f16 (head conv with the decode as its epilogue) against y5_conv_f16 followed by y5_detect_decode_f16 on
+    the same tensors: z and the permuted raw copy must agree -- identical wherever the two convolutions round alike, and
+    within the conv tolerance everywhere (the tile shapes, hence the fp32 summation orders, differ)."""
+    lib = _lib.lib()
+    B, Ci, ny, nx = shape
+    na, no = 3, 85
+    cout, cpad = na * no, 256
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, ny, nx, Ci, generator=g).half().to(dev)
+    w = torch.zeros(256, (Ci + 63) // 64 * 64, dtype=torch.float16, device=dev)
+    w[:cout, :Ci] = (torch.randn(cout, Ci, generator=g) / Ci ** 0.5).half().to(dev)
+    bias = torch.zeros(cpad, device=dev)
+    bias[:cout] = torch.randn(cout, generator=g).to(dev)
+    rows_total = na * ny * nx + 40          # the level sits at row offset 40 of a longer z
+    st = _lib.current_stream()
+
+    cd = _lib.ConvDesc()
+    cd.x, cd.w, cd.bias = x.data_ptr(), w.data_ptr(), bias.data_ptr()
+    cd.batch, cd.h, cd.w_in, cd.cin, cd.x_ld = B, ny, nx, Ci, Ci
+    cd.ho, cd.wo, cd.cout, cd.y_ld = ny, nx, cpad, cpad
+    cd.ksize, cd.stride, cd.pad, cd.kpad, cd.w_rows = 1, 1, 0, w.shape[1], 256
+    cd.act, cd.slope = _lib.ACT_NONE, 0.0
+
+    def dec_desc(x_out, z_out, head=None):
+        d = _lib.DecodeDesc()
+        d.x_out, d.z_out = x_out.data_ptr(), z_out.data_ptr()
+        if head is not None:
+            d.head, d.head_ld = head.data_ptr(), cpad
+        d.batch, d.ny, d.nx, d.na, d.no = B, ny, nx, na, no
+        d.z_rows_total, d.z_row0, d.stride = rows_total, 40, 16.0
+        for a, (aw, ah) in enumerate([(10., 13.), (16., 30.), (33., 23.)]):
+            d.anchor_wh[2 * a], d.anchor_wh[2 * a + 1] = aw, ah
+        return d
+
+    head = torch.zeros(B, ny, nx, cpad, dtype=torch.float16, device=dev)
+    cd.y = head.data_ptr()
+    _lib.check(lib.y5_conv_f16(C.byref(cd), st))
+    x_ref = torch.zeros(B, na, ny, nx, no, dtype=torch.float16, device=dev)
+    z_ref = torch.zeros(B, rows_total, no, dtype=torch.float16, device=dev)
+    _lib.check(lib.y5_detect_decode_f16(C.byref(dec_desc(x_ref, z_ref, head)), st))
+    cd.y = None
+    taken = 0
+    for v in range(lib.y5_detect_num_variants() + 1):
+        x_got = torch.full_like(x_ref, float('nan'))
+        z_got = torch.zeros_like(z_ref)
+        rc = lib.y5_detect_f16(C.byref(cd), C.byref(dec_desc(x_got, z_got)), v, st)
+        if (ny * nx * no) % 8:
+            assert rc == _lib.EINVAL, 'runs that are not 16-byte aligned belong to the two-kernel path'
+            continue
+        _lib.check(rc)
+        torch.cuda.synchronize()
+        taken += 1
+        assert not bool(torch.isnan(x_got).any())
+        assert bool((z_got[:, :40] == 0).all()), 'rows before the level must stay untouched'
+        for got, ref in ((x_got, x_ref), (z_got, z_ref)):
+            d = (got.float() - ref.float()).abs()
+            assert bool((d <= 2e-3 * ref.float().abs() + 2e-3 * ref.float().abs().max()).all()), float(d.max())
+        assert float((x_got == x_ref).float().mean()) > 0.97
+    assert taken == (0 if (ny * nx * no) % 8 else lib.y5_detect_num_variants() + 1)

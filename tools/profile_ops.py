@@ -34,7 +34,7 @@ tot = 0
 for r in acc:
     r['ms'] /= a.passes; tot += r['ms']
     if not a.summary: print('%3d %-8s %8.1f us %8.1f TF/s %8.0f GB/s  %s' % (r['op'], r['kind'], r['ms'] * 1e3, r['flops'] / r['ms'] / 1e9 if r['ms'] else 0, r['bytes'] / r['ms'] / 1e6 if r['ms'] else 0, r['label']))
-conv=[r for r in acc if r['kind'] in ('conv','focus_conv')]
+conv=[r for r in acc if r['kind'] in ('conv','focus_conv','detect')]
 cf=sum(r['flops'] for r in conv); cm=sum(r['ms'] for r in conv)
 print('%s batch %d: plan total %.3f ms, conv %.3f ms, %.1f GFLOP/img, conv aggregate %.1f TFLOP/s' % (a.model, a.batch, tot, cm, cf/a.batch/1e9, cf/cm/1e9))
 for r in sorted(conv, key=lambda r:-r['ms'])[:8]: print('   top: %7.1f us %7.1f TF/s %s' % (r['ms']*1e3, r['flops']/r['ms']/1e9, r['label']))

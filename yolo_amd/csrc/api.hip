@@ -85,6 +85,13 @@ extern "C" int y5_detect_decode_multi_f16(const y5_decode_desc* levels, int n_le
     return y5_launch_decode_multi(levels, n_levels, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int y5_detect_f16(const y5_conv_desc* conv, const y5_decode_desc* d, int variant, y5_stream_t stream) {
+    Y5_REQUIRE(conv && d, "detect: null descriptor");
+    return y5_launch_detect(*conv, *d, variant, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int y5_detect_num_variants(void) { return y5_detect_variant_count(); }
+
 // ------------------------------------------------------------------------------------------
 // launch plan
 // ------------------------------------------------------------------------------------------
@@ -166,6 +173,12 @@ bool set_ptr(Op& op, int field, const void* v) {
             else op.decm[l].z_out = nv;
             return true;
         }
+        case Y5_OP_DETECT:
+            if (field == 0) op.conv.x = v;
+            else if (field == 1) op.dec.x_out = nv;
+            else if (field == 2) op.dec.z_out = nv;
+            else return false;
+            return true;
         case Y5_OP_DECODE:
             if (field == 0) op.dec.head = v;
             else if (field == 1) op.dec.x_out = nv;
@@ -194,6 +207,7 @@ int run_op(const Op& op, hipStream_t s) {
         case Y5_OP_COPY: return y5_launch_copy_channels(op.px, op.i[0], op.py, op.i[1], op.pixels, op.i[2], s);
         case Y5_OP_DECODE: return y5_launch_decode(op.dec, s);
         case Y5_OP_DECODE_MULTI: return y5_launch_decode_multi(op.decm, op.i[0], s);
+        case Y5_OP_DETECT: return y5_launch_detect(op.conv, op.dec, op.i[0], s);
     }
     return y5_fail(Y5_EINVAL, "plan: unknown op kind %d", op.kind);
 }
@@ -365,6 +379,26 @@ extern "C" int y5_plan_add_decode_multi(y5_plan* p, const y5_decode_desc* levels
             note_ptr(p, op, 3 * l + 2, d.z_out);
             op.bytes += (d.x_out ? 6.0 : 4.0) * d.batch * d.ny * d.nx * d.na * d.no;
         }
+        p->ops.push_back(op);
+        return Y5_OK;
+    });
+}
+
+extern "C" int y5_plan_add_detect(y5_plan* p, const y5_conv_desc* conv, const y5_decode_desc* d, int variant) {
+    Y5_REQUIRE(p && conv && d, "plan_add_detect: null argument");
+    return guarded([&]() {
+        Op op;
+        op.kind = Y5_OP_DETECT;
+        op.conv = *conv;
+        op.dec = *d;
+        op.i[0] = variant;
+        note_ptr(p, op, 0, conv->x);
+        note_ptr(p, op, 1, d->x_out);
+        note_ptr(p, op, 2, d->z_out);
+        const double m = (double)conv->batch * conv->h * conv->w_in, outs = (double)d->na * d->no;
+        op.flops = 2.0 * m * conv->cout * conv->cin;
+        // read the feature map and the weights once, write z (and the permuted raw copy, when asked for) once, fp16
+        op.bytes = 2.0 * (m * conv->cin + (double)conv->cout * conv->cin + (d->x_out ? 2.0 : 1.0) * m * outs);
         p->ops.push_back(op);
         return Y5_OK;
     });

@@ -13,6 +13,7 @@
 namespace {
 
 #include "conv_common.h"
+#include "decode_tile.h"
 
 // buffer_load_dwordx4 ... lds: the wave writes 1 KiB at the wave-uniform LDS address dst, lane i at dst + 16*i, from
 // descriptor base + voff (per lane) + soff (wave-uniform); a lane whose offset fails the descriptor's range check gets
@@ -44,8 +45,12 @@ struct LwCfg {
 // DIRECT: 1x1 stride 1 (output pixel m reads input pixel m); otherwise 3x3.
 // The loaders use buffer_load ... lds: one scalar descriptor per tensor, a 32-bit byte offset per lane, zeros from the
 // hardware's range check for chunks outside the image or past a tap's channels.
-template <int BM, int BN, int WM, int WN, int NL, int S, int BK, bool DIRECT>
-__global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_lw_kernel(const ConvArgs a) {
+// DETECT: the Detect head's 1x1 convolution with the box decode as its epilogue (models/yolo.py:32-46 in one kernel):
+// tiles are TP pixels of ONE image by all na*no channels, and instead of storing the NHWC tile the workgroup writes the
+// permuted raw copy x[i] and the decoded rows of z from it.
+template <int BM, int BN, int WM, int WN, int NL, int S, int BK, bool DIRECT, bool DETECT = false>
+__global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_lw_kernel(const ConvArgs a, const DecodeArgs dec) {
+    static_assert(!DETECT || (DIRECT && BM == TP), "the decoding epilogue works on TP-pixel tiles of a 1x1 convolution");
     typedef LwCfg<BM, BN, WM, WN, NL, S, BK> Cfg;
     constexpr int NWC = WM * WN, NT = Cfg::NT;
     static_assert(BK == 32 || BK == 64, "K-step is 32 or 64");
@@ -67,8 +72,16 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_lw_kernel(const Conv
 
     const int tile = xcd_remap(blockIdx.x, a.tiles_total);
     const int mt = tile / a.tiles_n, nt = tile - mt * a.tiles_n;
-    const int m0 = mt * BM;
+    int m0 = mt * BM;
     const int n0 = nt * BN;
+    int rows_valid = BM, det_b = 0, det_pix0 = 0;  // DETECT: image, first pixel and pixel count of this tile
+    if constexpr (DETECT) {
+        const int npix = dec.ny * dec.nx;
+        det_b = mt / dec.tiles_per_image;
+        det_pix0 = (mt - det_b * dec.tiles_per_image) * BM;
+        rows_valid = npix - det_pix0 < BM ? npix - det_pix0 : BM;
+        m0 = det_b * npix + det_pix0;
+    }
     float* prm = reinterpret_cast<float*>(smem + Cfg::PRM0);
     const EpiParams epi = epi_fetch(a, n0, t, BN);
     epi_store(prm, epi, t, BN);  // published by the barriers of the K loop
@@ -90,7 +103,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_lw_kernel(const Conv
             const int kc = (lane % CPRW) ^ ((BK == 64) ? ((row >> 1) & 7) : ((row >> 2) & 3));
             kc8[i] = kc * 8;
             const int m = m0 + row;
-            const bool mvalid = m < a.M;
+            const bool mvalid = DETECT ? row < rows_valid : m < a.M;
             const unsigned mm = mvalid ? (unsigned)m : 0u;
             vmask[i] = 0;
             if (DIRECT) {
@@ -209,6 +222,10 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_lw_kernel(const Conv
         }
     }
     __syncthreads();
+    if constexpr (DETECT) {
+        decode_from_lds<true, NT>(dec, det_b, det_pix0, rows_valid, reinterpret_cast<f16*>(smem));
+        return;
+    }
     // ---- all waves: 16-byte stores of the finished tile (+ residual)
     constexpr int CPR = BN / 8;    // 16-byte chunks per tile row
     constexpr int RPP = NT / CPR;  // rows per pass
@@ -253,9 +270,9 @@ int launch_lw(const ConvArgs& a0, bool direct, hipStream_t s) {
     }
     const dim3 grid((unsigned)total), block(Cfg::NT);
     if (direct)
-        hipLaunchKernelGGL((conv_lw_kernel<BM, BN, WM, WN, NL, S, BK, true>), grid, block, Cfg::SMEM, s, a);
+        hipLaunchKernelGGL((conv_lw_kernel<BM, BN, WM, WN, NL, S, BK, true>), grid, block, Cfg::SMEM, s, a, DecodeArgs{});
     else
-        hipLaunchKernelGGL((conv_lw_kernel<BM, BN, WM, WN, NL, S, BK, false>), grid, block, Cfg::SMEM, s, a);
+        hipLaunchKernelGGL((conv_lw_kernel<BM, BN, WM, WN, NL, S, BK, false>), grid, block, Cfg::SMEM, s, a, DecodeArgs{});
     Y5_LAUNCH_CHECK("conv_lw_kernel");
     return Y5_OK;
 }
@@ -273,7 +290,70 @@ const LwVariant kLw[] = {
 };
 #undef Y5_LW
 
+template <int WM, int WN, int NL, int S, int BK>
+int launch_detect(const ConvArgs& a0, const DecodeArgs& dec0, int batch, hipStream_t s) {
+    constexpr int BM = TP, BN = 256;
+    typedef LwCfg<BM, BN, WM, WN, NL, S, BK> Cfg;
+    static_assert(Cfg::PRM0 >= (int)((TP * (Cfg::EP / 2) + (TP + 1) * Y5_MAX_ANCHORS * 4) * sizeof(f16)), "tile + decoded box slots fit before the parameters");
+    ConvArgs a = a0;
+    DecodeArgs dec = dec0;
+    dec.lds_ld = Cfg::EP / 2;  // the conv epilogue's tile pitch
+    a.tiles_n = 1;
+    a.nk = (a.K + BK - 1) / BK;
+    const long long total = (long long)dec.tiles_per_image * batch;
+    if (total <= 0 || total > 0x7fffffffLL) return y5_fail(Y5_EINVAL, "detect: tile count %lld out of range", total);
+    a.tiles_total = (int)total;
+    static std::atomic<unsigned long long> attr_set{0};
+    const unsigned long long bit = 1ull << y5_current_device();
+    if (!(attr_set.load() & bit)) {
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lw_kernel<BM, BN, WM, WN, NL, S, BK, true, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+        attr_set.fetch_or(bit);
+    }
+    hipLaunchKernelGGL((conv_lw_kernel<BM, BN, WM, WN, NL, S, BK, true, true>), dim3((unsigned)total), dim3(Cfg::NT), Cfg::SMEM, s, a, dec);
+    Y5_LAUNCH_CHECK("conv_lw_kernel (detect)");
+    return Y5_OK;
+}
+
+typedef int (*DetectLaunch)(const ConvArgs&, const DecodeArgs&, int, hipStream_t);
+const DetectLaunch kDetect[] = {&launch_detect<2, 4, 8, 3, 64>, &launch_detect<2, 2, 4, 3, 32>, &launch_detect<2, 4, 4, 3, 32>, &launch_detect<2, 2, 4, 2, 64>};
+
 }  // namespace
+
+int y5_detect_variant_count() { return (int)(sizeof(kDetect) / sizeof(kDetect[0])); }
+
+// Detect level = 1x1 convolution (bias, no activation) + decode, one kernel.  conv.y is not written.
+int y5_launch_detect(const y5_conv_desc& c, const y5_decode_desc& d, int variant, hipStream_t s) {
+    Y5_REQUIRE(variant >= 0 && variant <= y5_detect_variant_count(), "detect: variant %d out of range 0..%d", variant, y5_detect_variant_count());
+    Y5_REQUIRE(c.x && c.w && d.z_out, "detect: null tensor pointer");
+    Y5_REQUIRE(c.ksize == 1 && c.stride == 1 && c.pad == 0, "detect: the head convolution is 1x1 stride 1");
+    Y5_REQUIRE(c.batch == d.batch && c.h == d.ny && c.w_in == d.nx && c.ho == d.ny && c.wo == d.nx, "detect: convolution and decode shapes differ");
+    Y5_REQUIRE(c.cin > 0 && c.cin % 8 == 0 && c.x_ld % 8 == 0 && c.x_ld >= c.cin, "detect: cin %d / x_ld %d must be multiples of 8", c.cin, c.x_ld);
+    Y5_REQUIRE(c.cout % 8 == 0 && c.cout >= d.na * d.no && c.cout <= 256, "detect: %d output channels for na*no = %d (at most 256)", c.cout, d.na * d.no);
+    Y5_REQUIRE(c.kpad % 64 == 0 && c.kpad >= c.cin && c.w_rows >= 256, "detect: weights must be packed to 256 rows of kpad >= cin");
+    Y5_REQUIRE(!c.res && !c.scale && c.act == Y5_ACT_NONE, "detect: the head convolution has a bias only");
+    Y5_REQUIRE(y5_aligned16(c.x) && y5_aligned16(c.w) && y5_aligned16(c.bias), "detect: pointers must be 16-byte aligned");
+    DecodeArgs dec;
+    size_t lds_bytes = 0;
+    bool vec = false;
+    if (int rc = prepare_level(d, dec, &lds_bytes, &vec)) return rc;
+    Y5_REQUIRE(vec, "detect: the fused kernel needs 16-byte aligned output runs (ny*nx*no, rows*no, row0*no multiples of 8)");
+    const long long xb = (((long long)c.batch * c.h * c.w_in - 1) * c.x_ld + c.cin) * 2, wb = (long long)c.w_rows * c.kpad * 2;
+    Y5_REQUIRE(xb < 0x7fffffffLL && wb < 0x7fffffffLL, "detect: tensors of 2 GiB or more");
+    ConvArgs a{};
+    a.x = static_cast<const f16*>(c.x);
+    a.w = static_cast<const f16*>(c.w);
+    a.bias = c.bias;
+    a.M = (long long)c.batch * c.h * c.w_in;
+    a.H = c.h; a.W = c.w_in; a.Cin = c.cin; a.x_ld = c.x_ld;
+    a.Ho = c.h; a.Wo = c.w_in; a.Cout = c.cout;
+    a.stride = 1; a.pad = 0; a.K = c.cin;
+    a.w_ld = c.kpad;
+    a.slope = 1.f;
+    a.x_bytes = (int)xb;
+    a.w_bytes = (int)wb;
+    return kDetect[variant > 0 ? variant - 1 : 0](a, dec, c.batch, s);
+}
 
 int y5_conv_lw_count() { return (int)(sizeof(kLw) / sizeof(kLw[0])); }
 

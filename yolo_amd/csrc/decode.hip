@@ -9,121 +9,11 @@
 
 namespace {
 
-constexpr int TP = 64;  // pixels per workgroup
-constexpr int kThreads = 256;
-
-struct DecodeArgs {
-    const f16* head;
-    f16* x_out;
-    f16* z_out;
-    int head_ld, ny, nx, na, no;
-    int z_rows_total, z_row0;
-    int tiles_per_image;
-    int lds_ld;  // halfs per staged pixel (multiple of 8)
-    float stride;
-    float anchor_wh[2 * Y5_MAX_ANCHORS];
-};
-
-// sigmoid in fp32, rounded once to fp16 like a half tensor's .sigmoid().  The hardware exp2 / reciprocal form below
-// gives the same fp16 as 1/(1 + expf(-x)) with IEEE division for every one of the 65536 fp16 inputs (checked
-// exhaustively by the tests through y5_sigmoid_f16), at 4 instructions instead of ~25.
-__device__ __forceinline__ f16 sigmoid_h(f16 v) {
-    return (f16)__builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-(float)v * 1.44269504088896341f));
-}
-__device__ __forceinline__ f16 sigmoid_h_libm(f16 v) { return (f16)(1.f / (1.f + expf(-(float)v))); }
+#include "decode_tile.h"
 
 __global__ __launch_bounds__(256) void sigmoid_kernel(const f16* __restrict__ x, f16* __restrict__ y, long long n, int libm) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) y[i] = libm ? sigmoid_h_libm(x[i]) : sigmoid_h(x[i]);
-}
-
-// One decoded element. o: output slot within the anchor record, (gx, gy): cell, (aw, ah): anchor.
-__device__ __forceinline__ f16 decode_one(f16 raw, int o, float gx, float gy, float aw, float ah, float stride) {
-    const f16 s = sigmoid_h(raw);
-    if (o >= 4) return s;
-    const f16 two_s = (f16)((float)s * 2.f);  // exact doubling, kept as an fp16 op
-    if (o < 2) {
-        const f16 c = (f16)((float)two_s - 0.5f);           // fp16 result of (y*2 - 0.5)
-        const float g = (float)c + (o == 0 ? gx : gy);      // promoted to fp32 by the fp32 grid
-        return (f16)(g * stride);                           // * fp32 stride, one rounding on store
-    }
-    const f16 sq = (f16)((float)two_s * (float)two_s);      // (y*2)**2 in fp16
-    return (f16)((float)sq * (o == 2 ? aw : ah));           // * fp16 anchor_grid, fp16 result
-}
-
-// One workgroup's work: tile `block` (TP pixels of one image) of the level described by a.
-template <bool VEC>
-__device__ __forceinline__ void decode_tile(const DecodeArgs& a, int block, f16* tile) {
-    const int b = block / a.tiles_per_image;
-    const int tp = block - b * a.tiles_per_image;
-    const int npix_img = a.ny * a.nx;
-    const int pix0 = tp * TP;
-    const int np = min(TP, npix_img - pix0);
-    const int vec_per_pix = a.lds_ld / 8;
-
-    // stage: np pixels x lds_ld halfs (head_ld >= lds_ld >= chans, so the vector loads stay in the row)
-    const f16* src = a.head + ((long long)b * npix_img + pix0) * a.head_ld;
-    for (int i = threadIdx.x; i < np * vec_per_pix; i += kThreads) {
-        const int p = i / vec_per_pix, v = i - p * vec_per_pix;
-        *reinterpret_cast<uint4*>(tile + p * a.lds_ld + v * 8) =
-            *reinterpret_cast<const uint4*>(src + (long long)p * a.head_ld + v * 8);
-    }
-    __syncthreads();
-
-    // The four box slots of every (pixel, anchor) are decoded first, densely (one value per thread), into a small LDS
-    // array: inside the 8-wide output windows below they would be a divergent branch that nearly every wave takes.
-    f16* boxdec = tile + TP * a.lds_ld;  // [TP + 1][na][4]; the extra row is only ever read, by a window's unused tail
-    if (VEC) {
-        for (int i = threadIdx.x; i < np * a.na * 4; i += kThreads) {
-            const int o = i & 3, pa = i >> 2;
-            const int p = pa / a.na, an = pa - p * a.na;
-            const int pix = pix0 + p;
-            const int gy = pix / a.nx, gx = pix - gy * a.nx;
-            boxdec[i] = decode_one(tile[p * a.lds_ld + an * a.no + o], o, (float)gx, (float)gy, a.anchor_wh[2 * an],
-                                   a.anchor_wh[2 * an + 1], a.stride);
-        }
-        __syncthreads();
-    }
-
-    const int run = np * a.no;  // contiguous outputs per anchor
-    for (int an = 0; an < a.na; ++an) {
-        const float aw = a.anchor_wh[2 * an], ah = a.anchor_wh[2 * an + 1];
-        const long long xbase = (((long long)b * a.na + an) * npix_img + pix0) * a.no;
-        const long long zbase = ((long long)b * a.z_rows_total + a.z_row0 + (long long)an * npix_img + pix0) * a.no;
-        const f16* col = tile + an * a.no;
-        if (VEC) {
-            for (int e0 = threadIdx.x * 8; e0 < run; e0 += kThreads * 8) {
-                int p = e0 / a.no, o = e0 - p * a.no;
-                f16x8 raw, dec;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const f16 r = e0 + e < run ? col[p * a.lds_ld + o] : (f16)0.f;
-                    const f16 bx = boxdec[(p * a.na + an) * 4 + (o & 3)];
-                    raw[e] = r;
-                    dec[e] = o < 4 ? bx : sigmoid_h(r);
-                    if (++o == a.no) { o = 0; ++p; }
-                }
-                if (e0 + 8 <= run) {
-                    if (a.x_out) *reinterpret_cast<f16x8*>(a.x_out + xbase + e0) = raw;
-                    *reinterpret_cast<f16x8*>(a.z_out + zbase + e0) = dec;
-                } else {
-                    for (int e = 0; e0 + e < run; ++e) {
-                        if (a.x_out) a.x_out[xbase + e0 + e] = raw[e];
-                        a.z_out[zbase + e0 + e] = dec[e];
-                    }
-                }
-            }
-        } else {
-            for (int e0 = threadIdx.x; e0 < run; e0 += kThreads) {
-                const int p = e0 / a.no, o = e0 - p * a.no;
-                const f16 r = col[p * a.lds_ld + o];
-                const int pix = pix0 + p;
-                const int gy = pix / a.nx, gx = pix - gy * a.nx;
-                if (a.x_out) a.x_out[xbase + e0] = r;
-                a.z_out[zbase + e0] = decode_one(r, o, (float)gx, (float)gy, aw, ah, a.stride);
-            }
-        }
-    }
 }
 
 template <bool VEC>
@@ -160,40 +50,13 @@ int y5_launch_sigmoid(const void* x, void* y, long long n, int libm, hipStream_t
 }
 
 namespace {
-
-// Validates one level and fills its kernel arguments; *vec says whether the 16-byte store path applies.
-int prepare_level(const y5_decode_desc& d, DecodeArgs& a, size_t* lds_bytes, bool* vec) {
-    Y5_REQUIRE(d.head && d.z_out, "decode: null pointer");
-    Y5_REQUIRE(d.batch > 0 && d.ny > 0 && d.nx > 0, "decode: empty tensor");
-    Y5_REQUIRE(d.na >= 1 && d.na <= Y5_MAX_ANCHORS, "decode: na %d out of range 1..%d", d.na, Y5_MAX_ANCHORS);
-    Y5_REQUIRE(d.no >= 5, "decode: no %d < 5", d.no);
-    const int chans = d.na * d.no;
-    const int lds_ld = (chans + 7) / 8 * 8;
-    Y5_REQUIRE(d.head_ld % 8 == 0 && d.head_ld >= lds_ld, "decode: head_ld %d must be a multiple of 8 >= %d", d.head_ld, lds_ld);
+// The stand-alone kernels read the head values from memory.
+int check_head(const y5_decode_desc& d, const DecodeArgs& a) {
+    Y5_REQUIRE(d.head, "decode: null pointer");
+    Y5_REQUIRE(d.head_ld % 8 == 0 && d.head_ld >= a.lds_ld, "decode: head_ld %d must be a multiple of 8 >= %d", d.head_ld, a.lds_ld);
     Y5_REQUIRE(y5_aligned16(d.head), "decode: head must be 16-byte aligned");
-    Y5_REQUIRE(d.z_row0 >= 0 && (long long)d.z_row0 + (long long)d.na * d.ny * d.nx <= d.z_rows_total, "decode: rows %d..+%d exceed z_rows_total %d", d.z_row0, d.na * d.ny * d.nx, d.z_rows_total);
-    *lds_bytes = ((size_t)TP * lds_ld + (size_t)(TP + 1) * d.na * 4) * sizeof(f16);  // staged pixels + decoded box slots
-    Y5_REQUIRE(*lds_bytes <= 64 * 1024, "decode: na*no = %d too large for the staging tile", chans);
-
-    a.head = static_cast<const f16*>(d.head);
-    a.x_out = static_cast<f16*>(d.x_out);
-    a.z_out = static_cast<f16*>(d.z_out);
-    a.head_ld = d.head_ld; a.ny = d.ny; a.nx = d.nx; a.na = d.na; a.no = d.no;
-    a.z_rows_total = d.z_rows_total; a.z_row0 = d.z_row0;
-    const int npix = d.ny * d.nx;
-    a.tiles_per_image = (npix + TP - 1) / TP;
-    a.lds_ld = lds_ld;
-    a.stride = d.stride;
-    for (int i = 0; i < 2 * Y5_MAX_ANCHORS; ++i) a.anchor_wh[i] = d.anchor_wh[i];
-    Y5_REQUIRE((long long)a.tiles_per_image * d.batch < 0x7fffffffLL, "decode: too many tiles");
-
-    // 16-byte stores need every per-anchor run to start on a multiple of 8 elements in both tensors:
-    // runs start at ((b*na + an)*npix + pix0)*no and (b*rows + row0 + an*npix + pix0)*no with pix0 % 64 == 0.
-    *vec = (((long long)npix * d.no) % 8 == 0) && (((long long)d.z_rows_total * d.no) % 8 == 0) &&
-           (((long long)d.z_row0 * d.no) % 8 == 0) && y5_aligned16(d.z_out) && y5_aligned16(d.x_out);
     return Y5_OK;
 }
-
 }  // namespace
 
 int y5_launch_decode(const y5_decode_desc& d, hipStream_t s) {
@@ -201,6 +64,7 @@ int y5_launch_decode(const y5_decode_desc& d, hipStream_t s) {
     size_t lds_bytes = 0;
     bool vec = false;
     if (int rc = prepare_level(d, a, &lds_bytes, &vec)) return rc;
+    if (int rc = check_head(d, a)) return rc;
     const dim3 grid((unsigned)(a.tiles_per_image * d.batch));
     if (vec)
         hipLaunchKernelGGL(detect_decode_kernel<true>, grid, dim3(kThreads), lds_bytes, s, a);
@@ -221,6 +85,7 @@ int y5_launch_decode_multi(const y5_decode_desc* d, int n, hipStream_t s) {
         size_t lds_bytes = 0;
         bool vec = false;
         if (int rc = prepare_level(d[l], m.lv[l], &lds_bytes, &vec)) return rc;
+        if (int rc = check_head(d[l], m.lv[l])) return rc;
         vec_all = vec_all && vec;
         if (lds_bytes > lds_max) lds_max = lds_bytes;
         m.first_block[l] = (int)blocks;

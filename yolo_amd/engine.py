@@ -631,6 +631,40 @@ class Plan:
             self.labels[-1] += ' (side stream)'
         self.head_bufs[lvl] = headbuf
 
+    def _detect_fused(self, m, lvl, f, dd):
+        """Descriptors of Detect level lvl as one kernel (y5_detect_f16: 1x1 conv + decode, models/yolo.py:32-46), with
+        the fastest tile configuration for the shape; None when the kernel does not take the level."""
+        conv = m.m[lvl]
+        cout = m.na * m.no
+        if conv.out_channels != cout or pad8(cout) > 256 or conv.bias is None or _conv_geometry(conv) != (1, 1):
+            return None
+        packed, kpad, rows = self._pack_weight([(conv.weight, pad8(cout))], f.segs)
+        cd = _lib.ConvDesc()
+        cd.x, cd.w = f.ptr, packed.data_ptr()
+        cd.bias = self._f32(conv.bias, pad8(cout)).data_ptr()
+        cd.batch, cd.h, cd.w_in, cd.cin, cd.x_ld = f.batch, f.h, f.w, f.c_pad, f.ld
+        cd.ho, cd.wo, cd.cout, cd.y_ld = f.h, f.w, pad8(cout), pad8(cout)
+        cd.ksize, cd.stride, cd.pad, cd.kpad, cd.w_rows = 1, 1, 0, kpad, rows
+        cd.act, cd.slope = _lib.ACT_NONE, 0.0
+        stream = _lib.current_stream()
+        if self.lib.y5_detect_f16(C.byref(cd), C.byref(dd), 0, stream) != 0:
+            return None
+        best, best_t = 0, float('inf')
+        if os.environ.get('Y5_AUTOTUNE', '1') != '0':
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for v in range(1, self.lib.y5_detect_num_variants() + 1):
+                if self.lib.y5_detect_f16(C.byref(cd), C.byref(dd), v, stream) != 0:
+                    continue
+                e0.record()
+                for _ in range(4):
+                    self.lib.y5_detect_f16(C.byref(cd), C.byref(dd), v, stream)
+                e1.record()
+                e1.synchronize()
+                if e0.elapsed_time(e1) < best_t:
+                    best, best_t = v, e0.elapsed_time(e1)
+        label = 'detect.m%d conv1x1+decode %d->%d @%dx%d v%d' % (lvl, f.c_log, cout, f.h, f.w, best)
+        return label, cd, dd, best
+
     def _detect(self, m, feats):
         B = self.batch
         na, no = m.na, m.no
@@ -647,14 +681,9 @@ class Plan:
             _lib.check(self.lib.y5_plan_bind_slot(self.handle, 2 + i, t.data_ptr(), t.numel() * 2))
         row0 = 0
         anchor_grid = m.anchor_grid.detach().float().cpu().view(m.nl, na, 2)
-        fused = len(feats) <= _lib.Y5_MAX_LEVELS and os.environ.get('Y5_DECODE_FUSE', '1') != '0'
-        levels = (_lib.DecodeDesc * len(feats))()
-        for i, f in enumerate(feats):
-            if i not in self.head_bufs:
-                self._detect_conv(m, i, f)
-            headbuf = self.head_bufs[i]
+
+        def decode_desc(i, f, row0):
             d = _lib.DecodeDesc()
-            d.head, d.head_ld = headbuf.ptr, headbuf.ld
             d.x_out, d.z_out = xs[i].data_ptr(), z.data_ptr()
             d.batch, d.ny, d.nx, d.na, d.no = B, f.h, f.w, na, no
             d.z_rows_total, d.z_row0 = self.z_shape[1], row0
@@ -662,6 +691,31 @@ class Plan:
             for a in range(na):
                 d.anchor_wh[2 * a] = float(anchor_grid[i, a, 0])
                 d.anchor_wh[2 * a + 1] = float(anchor_grid[i, a, 1])
+            return d
+
+        # Every level as ONE kernel (head conv with the decode as its epilogue) when all of them qualify and none was
+        # already recorded on the side stream; otherwise head convs + one decode launch.
+        if not self.head_bufs and os.environ.get('Y5_DETECT_FUSE', '1') != '0':
+            ops, r0 = [], 0
+            for i, f in enumerate(feats):
+                op = self._detect_fused(m, i, f, decode_desc(i, f, r0))
+                if op is None:
+                    break
+                ops.append(op)
+                r0 += rows[i]
+            if len(ops) == len(feats):
+                for label, cd, dd, variant in ops:
+                    _lib.check(self.lib.y5_plan_add_detect(self.handle, C.byref(cd), C.byref(dd), variant))
+                    self.labels.append(label)
+                return
+        fused = len(feats) <= _lib.Y5_MAX_LEVELS and os.environ.get('Y5_DECODE_FUSE', '1') != '0'
+        levels = (_lib.DecodeDesc * len(feats))()
+        for i, f in enumerate(feats):
+            if i not in self.head_bufs:
+                self._detect_conv(m, i, f)
+            headbuf = self.head_bufs[i]
+            d = decode_desc(i, f, row0)
+            d.head, d.head_ld = headbuf.ptr, headbuf.ld
             if fused:
                 C.memmove(C.byref(levels[i]), C.byref(d), C.sizeof(_lib.DecodeDesc))
             else:
