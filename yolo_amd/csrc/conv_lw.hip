@@ -316,7 +316,8 @@ int launch_detect(const ConvArgs& a0, const DecodeArgs& dec0, int batch, hipStre
 }
 
 typedef int (*DetectLaunch)(const ConvArgs&, const DecodeArgs&, int, hipStream_t);
-const DetectLaunch kDetect[] = {&launch_detect<2, 4, 8, 3, 64>, &launch_detect<2, 2, 4, 3, 32>, &launch_detect<2, 4, 4, 3, 32>, &launch_detect<2, 2, 4, 2, 64>};
+const DetectLaunch kDetect[] = {&launch_detect<2, 4, 8, 3, 64>, &launch_detect<2, 2, 4, 3, 32>, &launch_detect<2, 4, 4, 3, 32>, &launch_detect<2, 2, 4, 2, 64>,
+                                &launch_detect<2, 2, 4, 2, 32>, &launch_detect<2, 4, 4, 2, 32>, &launch_detect<1, 4, 4, 2, 32>};
 
 }  // namespace
 
