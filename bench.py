@@ -73,7 +73,7 @@ def main():
     rank, world, local = ydist.init_from_env()
     if world != args.gpus:
         raise SystemExit('bench: --gpus %d but WORLD_SIZE is %d (launch N>1 with torch.distributed.run)' % (args.gpus, world))
-    device = torch.device('cuda', local)
+    device = torch.device('cuda', local % max(1, torch.cuda.device_count()))  # ranks share devices only in a rehearsal
     torch.cuda.set_device(device)
     torch.set_grad_enabled(False)
 
@@ -109,7 +109,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if dist.get_backend() == 'gloo' else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     det, count, ncand = out

@@ -50,7 +50,7 @@ struct LwCfg {
 // permuted raw copy x[i] and the decoded rows of z from it.
 template <int BM, int BN, int WM, int WN, int NL, int S, int BK, bool DIRECT, bool DETECT = false>
 __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_lw_kernel(const ConvArgs a, const DecodeArgs dec) {
-    static_assert(!DETECT || (DIRECT && BM == TP), "the decoding epilogue works on TP-pixel tiles of a 1x1 convolution");
+    static_assert(!DETECT || (DIRECT && BM % TP == 0), "the decoding epilogue works on TP-pixel slices of a 1x1 convolution's tile");
     typedef LwCfg<BM, BN, WM, WN, NL, S, BK> Cfg;
     constexpr int NWC = WM * WN, NT = Cfg::NT;
     static_assert(BK == 32 || BK == 64, "K-step is 32 or 64");
@@ -223,7 +223,15 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_lw_kernel(const Conv
     }
     __syncthreads();
     if constexpr (DETECT) {
-        decode_from_lds<true, NT>(dec, det_b, det_pix0, rows_valid, reinterpret_cast<f16*>(smem));
+        f16* tile = reinterpret_cast<f16*>(smem);
+        f16* boxdec = reinterpret_cast<f16*>(smem + Cfg::SMEM);  // the launcher adds DETECT_EXTRA bytes behind the parameters
+#pragma unroll
+        for (int sub = 0; sub < BM / TP; ++sub) {
+            const int np = rows_valid - sub * TP < TP ? rows_valid - sub * TP : TP;  // workgroup-uniform
+            if (np <= 0) break;
+            if (sub) __syncthreads();  // the box slots of the previous slice are consumed
+            decode_from_lds<true, NT>(dec, det_b, det_pix0 + sub * TP, np, tile + sub * TP * (EP / 2), boxdec);
+        }
         return;
     }
     // ---- all waves: 16-byte stores of the finished tile (+ residual)
@@ -290,14 +298,16 @@ const LwVariant kLw[] = {
 };
 #undef Y5_LW
 
-template <int WM, int WN, int NL, int S, int BK>
+constexpr int DETECT_EXTRA = (TP + 1) * Y5_MAX_ANCHORS * 4 * (int)sizeof(f16);  // decoded box slots behind the parameters
+
+template <int BM, int WM, int WN, int NL, int S, int BK>
 int launch_detect(const ConvArgs& a0, const DecodeArgs& dec0, int batch, hipStream_t s) {
-    constexpr int BM = TP, BN = 256;
+    constexpr int BN = 256;
     typedef LwCfg<BM, BN, WM, WN, NL, S, BK> Cfg;
-    static_assert(Cfg::PRM0 >= (int)((TP * (Cfg::EP / 2) + (TP + 1) * Y5_MAX_ANCHORS * 4) * sizeof(f16)), "tile + decoded box slots fit before the parameters");
     ConvArgs a = a0;
     DecodeArgs dec = dec0;
     dec.lds_ld = Cfg::EP / 2;  // the conv epilogue's tile pitch
+    dec.tiles_per_image = (dec.ny * dec.nx + BM - 1) / BM;  // tiles of BM pixels of one image here
     a.tiles_n = 1;
     a.nk = (a.K + BK - 1) / BK;
     const long long total = (long long)dec.tiles_per_image * batch;
@@ -307,17 +317,18 @@ int launch_detect(const ConvArgs& a0, const DecodeArgs& dec0, int batch, hipStre
     const unsigned long long bit = 1ull << y5_current_device();
     if (!(attr_set.load() & bit)) {
         Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lw_kernel<BM, BN, WM, WN, NL, S, BK, true, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM + DETECT_EXTRA));
         attr_set.fetch_or(bit);
     }
-    hipLaunchKernelGGL((conv_lw_kernel<BM, BN, WM, WN, NL, S, BK, true, true>), dim3((unsigned)total), dim3(Cfg::NT), Cfg::SMEM, s, a, dec);
+    hipLaunchKernelGGL((conv_lw_kernel<BM, BN, WM, WN, NL, S, BK, true, true>), dim3((unsigned)total), dim3(Cfg::NT), Cfg::SMEM + DETECT_EXTRA, s, a, dec);
     Y5_LAUNCH_CHECK("conv_lw_kernel (detect)");
     return Y5_OK;
 }
 
 typedef int (*DetectLaunch)(const ConvArgs&, const DecodeArgs&, int, hipStream_t);
-const DetectLaunch kDetect[] = {&launch_detect<2, 4, 8, 3, 64>, &launch_detect<2, 2, 4, 3, 32>, &launch_detect<2, 4, 4, 3, 32>, &launch_detect<2, 2, 4, 2, 64>,
-                                &launch_detect<2, 2, 4, 2, 32>, &launch_detect<2, 4, 4, 2, 32>, &launch_detect<1, 4, 4, 2, 32>};
+const DetectLaunch kDetect[] = {&launch_detect<64, 2, 4, 4, 2, 32>, &launch_detect<64, 2, 4, 4, 3, 32>, &launch_detect<64, 2, 2, 4, 3, 32>,
+                                &launch_detect<64, 2, 4, 8, 3, 64>, &launch_detect<64, 2, 2, 2, 2, 32>, &launch_detect<64, 2, 2, 4, 2, 32>,
+                                &launch_detect<64, 1, 4, 4, 2, 32>};
 
 }  // namespace
 

@@ -40,16 +40,16 @@ __device__ __forceinline__ f16 decode_one(f16 raw, int o, float gx, float gy, fl
 }
 
 // Decodes np <= TP consecutive pixels (from pix0, a multiple of TP) of image b whose head values lie in LDS at
-// tile[p * a.lds_ld + channel]; the caller has synchronised the workgroup (NTH threads) after filling the tile, and
-// (TP + 1) * na * 4 halfs behind TP * a.lds_ld are free for the decoded box slots.
+// tile[p * a.lds_ld + channel]; the caller has synchronised the workgroup (NTH threads) after filling the tile.
+// boxdec: (TP + 1) * na * 4 halfs of LDS for the decoded box slots.  Row TP of the tile may be read (never used).
 template <bool VEC, int NTH>
-__device__ __forceinline__ void decode_from_lds(const DecodeArgs& a, int b, int pix0, int np, f16* tile) {
+__device__ __forceinline__ void decode_from_lds(const DecodeArgs& a, int b, int pix0, int np, f16* tile, f16* boxdec) {
     constexpr int kThreads = NTH;
     const int npix_img = a.ny * a.nx;
 
     // The four box slots of every (pixel, anchor) are decoded first, densely (one value per thread), into a small LDS
     // array: inside the 8-wide output windows below they would be a divergent branch that nearly every wave takes.
-    f16* boxdec = tile + TP * a.lds_ld;  // [TP + 1][na][4]; the extra row is only ever read, by a window's unused tail
+    // boxdec is [TP + 1][na][4]; the extra row is only ever read, by a window's unused tail
     if (VEC) {
         for (int i = threadIdx.x; i < np * a.na * 4; i += kThreads) {
             const int o = i & 3, pa = i >> 2;
@@ -69,16 +69,28 @@ __device__ __forceinline__ void decode_from_lds(const DecodeArgs& a, int b, int 
         const long long zbase = ((long long)b * a.z_rows_total + a.z_row0 + (long long)an * npix_img + pix0) * a.no;
         const f16* col = tile + an * a.no;
         if (VEC) {
+            // A window of 8 consecutive outputs lies in pixel p from slot o on and, past that pixel's last slot, in pixel
+            // p + 1 from slot 0 on (no >= 8).  Every element gets the sigmoid; the few windows that touch a pixel's four
+            // box slots are patched from the pre-decoded array afterwards.
+            const int skip = a.lds_ld - a.no;
             for (int e0 = threadIdx.x * 8; e0 < run; e0 += kThreads * 8) {
-                int p = e0 / a.no, o = e0 - p * a.no;
+                const int p = e0 / a.no, o = e0 - p * a.no;
+                const int n1 = a.no - o;  // elements e >= n1 belong to pixel p + 1
+                const f16* src = col + p * a.lds_ld + o;
                 f16x8 raw, dec;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const f16 r = e0 + e < run ? col[p * a.lds_ld + o] : (f16)0.f;
-                    const f16 bx = boxdec[(p * a.na + an) * 4 + (o & 3)];
+                    const f16 r = src[e + (e >= n1 ? skip : 0)];  // past the run's end: LDS behind the tile, never stored
                     raw[e] = r;
-                    dec[e] = o < 4 ? bx : sigmoid_h(r);
-                    if (++o == a.no) { o = 0; ++p; }
+                    dec[e] = sigmoid_h(r);
+                }
+                if (o < 4 || n1 < 8) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int oe = e < n1 ? o + e : e - n1;
+                        const int pe = e < n1 ? p : p + 1;
+                        if (oe < 4) dec[e] = boxdec[(pe * a.na + an) * 4 + oe];
+                    }
                 }
                 if (e0 + 8 <= run) {
                     if (a.x_out) *reinterpret_cast<f16x8*>(a.x_out + xbase + e0) = raw;
@@ -120,7 +132,7 @@ __device__ __forceinline__ void decode_tile(const DecodeArgs& a, int block, f16*
             *reinterpret_cast<const uint4*>(src + (long long)p * a.head_ld + v * 8);
     }
     __syncthreads();
-    decode_from_lds<VEC, kThreads>(a, b, pix0, np, tile);
+    decode_from_lds<VEC, kThreads>(a, b, pix0, np, tile, tile + TP * a.lds_ld);
 }
 
 // Validates one level and fills its kernel arguments; *vec says whether the 16-byte store path applies.

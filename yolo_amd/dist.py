@@ -21,8 +21,8 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend is None:  # Y5_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
+            backend = os.environ.get('Y5_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -58,6 +58,11 @@ def gather_detections(det, count, group=None):
         return det, count
     world = dist.get_world_size(group)
     block = pack_detections(det, count)
+    if block.is_cuda and dist.get_backend(group) == 'gloo':  # rehearsal on a CPU collective: stage through the host
+        host = block.cpu()
+        out = torch.empty((world * host.shape[0], host.shape[1]), dtype=host.dtype)
+        dist.all_gather_into_tensor(out, host, group=group)
+        return unpack_detections(out.to(block.device), det.shape[1])
     out = torch.empty((world * block.shape[0], block.shape[1]), dtype=block.dtype, device=block.device)
     dist.all_gather_into_tensor(out, block, group=group)
     return unpack_detections(out, det.shape[1])
