@@ -88,6 +88,18 @@ int y5_conv_f16(const y5_conv_desc* d, y5_stream_t stream);
  * fastest; an id that does not apply to the shape returns Y5_EINVAL. */
 int y5_conv_num_variants(void);
 
+/* Two convolutions in one kernel: `first` (3x3, or 1x1 stride 1; all post-ops of y5_conv_f16 including the residual)
+ * followed by `second`, a 1x1 stride-1 convolution of first's output (bias / scale+shift / activation, no residual):
+ *     second.y = post2(W2 . first_result)
+ * with first_result rounded to fp16 exactly as y5_conv_f16 would store it.  Replaces two consecutive Conv.forward /
+ * nn.Conv2d calls (models/common.py:26, :43, :61: the last Bottleneck's cv2 followed by BottleneckCSP.cv3) without the
+ * intermediate tensor: first.y is written only if keep_first != 0 (it may be NULL otherwise); second.x is ignored.
+ * Both channel counts must fit one tile of the chosen variant (at most 256; Y5_EINVAL otherwise) and both weight
+ * tensors must be packed to that many rows.  variant: 0 or 1..y5_conv_chain_num_variants().  Same values as the two
+ * separate calls up to the fp32 summation order. */
+int y5_conv_chain_f16(const y5_conv_desc* first, const y5_conv_desc* second, int keep_first, int variant, y5_stream_t stream);
+int y5_conv_chain_num_variants(void);
+
 /* Focus followed by its 3x3 stride-1 pad-1 convolution, straight from the NCHW image, without materialising the
  * space-to-depth tensor.  Replaces: Focus.forward  models/common.py:85-86 (four strided slices + cat + self.conv).
  * Same descriptor and post-ops as y5_conv_f16 with these meanings: x = image (batch, cin = 3, h, w_in) fp16 NCHW
@@ -274,6 +286,7 @@ int y5_plan_add_copy_channels(y5_plan* p, const void* x, int x_ld, void* y, int 
 int y5_plan_add_decode(y5_plan* p, const y5_decode_desc* d);
 int y5_plan_add_decode_multi(y5_plan* p, const y5_decode_desc* levels, int n_levels);
 int y5_plan_add_detect(y5_plan* p, const y5_conv_desc* conv, const y5_decode_desc* d, int variant);
+int y5_plan_add_conv_chain(y5_plan* p, const y5_conv_desc* first, const y5_conv_desc* second, int keep_first, int variant);
 /* Mark the op recorded last.  Y5_PLAN_SIDE: y5_plan_run launches it on a second stream owned by the plan, ordered
  * after everything issued before it on the caller's stream -- for an op whose result is needed only much later (the
  * Detect convs of the finer pyramid levels, which can run beside the rest of the head).  Y5_PLAN_JOIN: the caller's
@@ -301,6 +314,7 @@ int y5_plan_profile(y5_plan* p, void* const* ext, int n_ext, y5_stream_t stream,
 #define Y5_OP_FOCUS_CONV_U8 10
 #define Y5_OP_NORMALIZE_U8 11
 #define Y5_OP_DETECT 12
+#define Y5_OP_CONV_CHAIN 13
 int y5_plan_op_info(const y5_plan* p, int i, int* kind, double* flops, double* bytes);
 
 #ifdef __cplusplus

@@ -305,3 +305,90 @@ def test_input_of_two_gib_or_more_is_convolved_in_image_slices(dev):
         assert torch.equal(whole[b], conv(x[b:b + 1])[0])
     ref = (x[8, :64, :64].float() @ w.float().t()).half()
     close(whole[8, :64, :64].permute(2, 0, 1)[None], ref.permute(2, 0, 1)[None])
+
+
+def _desc(dev, x_nhwc, w, bias=None, scale=None, shift=None, slope=None, res=None, stride=1, keep=None):
+    """y5_conv_desc for NHWC fp16 x (B,H,W,Cpad) and weights (Co,Ci,k,k); returns (desc, output tensor, objects to keep)."""
+    B, H, W, cip = x_nhwc.shape
+    Co, Ci, k, _ = w.shape
+    cop = (Co + 7) // 8 * 8
+    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    kk = k * k * cip
+    kpad = (kk + 63) // 64 * 64
+    wp = torch.zeros(256, kpad, dtype=torch.float16, device=dev)
+    wv = torch.zeros(Co, k, k, cip, dtype=torch.float16, device=dev)
+    wv[..., :Ci] = w.permute(0, 2, 3, 1)
+    wp[:Co, :kk] = wv.reshape(Co, kk)
+    y = torch.full((B, Ho, Wo, cop), float('nan'), dtype=torch.float16, device=dev)
+    keep = [wp, y]
+
+    def vec(t):
+        if t is None:
+            return None
+        v = torch.zeros(cop, dtype=torch.float32, device=dev)
+        v[:Co] = t.float()
+        keep.append(v)
+        return v.data_ptr()
+    d = _lib.ConvDesc()
+    d.x, d.w, d.y = x_nhwc.data_ptr(), wp.data_ptr(), y.data_ptr()
+    d.bias, d.scale, d.shift = vec(bias), vec(scale), vec(shift)
+    if res is not None:
+        d.res, d.res_ld = res.data_ptr(), res.shape[-1]
+    d.batch, d.h, d.w_in, d.cin, d.x_ld = B, H, W, cip, cip
+    d.ho, d.wo, d.cout, d.y_ld = Ho, Wo, cop, cop
+    d.ksize, d.stride, d.pad, d.kpad, d.w_rows = k, stride, k // 2, kpad, 256
+    d.act, d.slope = (_lib.ACT_LEAKY, slope) if slope is not None else (_lib.ACT_NONE, 0.0)
+    return d, y, keep
+
+
+@pytest.mark.parametrize('shape', [(2, 32, 32, 32, 40, 24, 3, 1), (3, 64, 64, 64, 20, 20, 3, 1), (1, 128, 128, 128, 20, 12, 3, 1),
+                                   (2, 24, 40, 56, 17, 9, 3, 1), (2, 64, 64, 32, 24, 24, 1, 1), (1, 64, 128, 64, 16, 16, 3, 2)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_conv_chain_equals_two_convolutions(dev, shape):
+    """y5_conv_chain_f16 (conv + residual, then a 1x1 conv of the result, one kernel) against the same two convolutions
+    as separate y5_conv_f16 calls: equal within the conv tolerance for every tile shape that holds both channel counts,
+    with and without the intermediate tensor being stored."""
+    lib = _lib.lib()
+    B, Ci, Cm, Co, H, W, k, s = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    st = _lib.current_stream()
+    cip = (Ci + 7) // 8 * 8
+    x = torch.zeros(B, H, W, cip, dtype=torch.float16, device=dev)
+    x[..., :Ci] = torch.randn(B, H, W, Ci, generator=g).half().to(dev)
+    w1 = (torch.randn(Cm, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5).half().to(dev)
+    w2 = (torch.randn(Co, Cm, 1, 1, generator=g) / Cm ** 0.5).half().to(dev)
+    b1 = torch.randn(Cm, generator=g).to(dev)
+    sc2, sh2 = (torch.rand(Co, generator=g) + 0.5).to(dev), torch.randn(Co, generator=g).to(dev)
+    Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+    cmp_ = (Cm + 7) // 8 * 8
+    res = torch.zeros(B, Ho, Wo, cmp_, dtype=torch.float16, device=dev)
+    res[..., :Cm] = torch.randn(B, Ho, Wo, Cm, generator=g).half().to(dev)
+    for use_res in (True, False):
+        d1, y1, k1 = _desc(dev, x, w1, bias=b1, slope=0.1, res=res if use_res else None, stride=s)
+        _lib.check(lib.y5_conv_f16(C.byref(d1), st))
+        d2, y2, k2 = _desc(dev, y1, w2, scale=sc2, shift=sh2, slope=0.1)
+        _lib.check(lib.y5_conv_f16(C.byref(d2), st))
+        torch.cuda.synchronize()
+        y1_ref, y2_ref = y1.clone(), y2.clone()
+        taken = 0
+        for v in range(lib.y5_conv_chain_num_variants() + 1):
+            for keep_first in (1, 0):
+                y1.fill_(float('nan'))
+                y2.fill_(float('nan'))
+                if not keep_first:
+                    d1.y = None
+                else:
+                    d1.y = y1.data_ptr()
+                rc = lib.y5_conv_chain_f16(C.byref(d1), C.byref(d2), keep_first, v, st)
+                if v and rc == _lib.EINVAL:
+                    continue
+                _lib.check(rc)
+                torch.cuda.synchronize()
+                taken += 1
+                if keep_first:
+                    close(y1.permute(0, 3, 1, 2), y1_ref.permute(0, 3, 1, 2))
+                else:
+                    assert bool(torch.isnan(y1).all()), 'the intermediate tensor must not be written'
+                assert not bool(torch.isnan(y2).any())
+                close(y2.permute(0, 3, 1, 2), y2_ref.permute(0, 3, 1, 2), rel=4e-3)
+        assert taken >= 4

@@ -92,6 +92,13 @@ extern "C" int y5_detect_f16(const y5_conv_desc* conv, const y5_decode_desc* d, 
 
 extern "C" int y5_detect_num_variants(void) { return y5_detect_variant_count(); }
 
+extern "C" int y5_conv_chain_f16(const y5_conv_desc* first, const y5_conv_desc* second, int keep_first, int variant, y5_stream_t stream) {
+    Y5_REQUIRE(first && second, "conv chain: null descriptor");
+    return y5_launch_conv_chain(*first, *second, keep_first, variant, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int y5_conv_chain_num_variants(void) { return y5_conv_lw_count(); }
+
 // ------------------------------------------------------------------------------------------
 // launch plan
 // ------------------------------------------------------------------------------------------
@@ -111,6 +118,7 @@ struct PtrFix {  // pointer field of an op that must be rebased on an external s
 struct Op {
     int kind = 0;
     y5_conv_desc conv{};
+    y5_conv_desc conv2{};  // Y5_OP_CONV_CHAIN: the second convolution; i[0] variant, i[1] keep_first
     y5_decode_desc dec{};
     y5_decode_desc decm[Y5_MAX_LEVELS] = {};  // Y5_OP_DECODE_MULTI: i[0] levels
     // generic pointwise arguments
@@ -173,6 +181,13 @@ bool set_ptr(Op& op, int field, const void* v) {
             else op.decm[l].z_out = nv;
             return true;
         }
+        case Y5_OP_CONV_CHAIN:
+            if (field == 0) op.conv.x = v;
+            else if (field == 1) op.conv.y = nv;
+            else if (field == 2) op.conv.res = v;
+            else if (field == 3) op.conv2.y = nv;
+            else return false;
+            return true;
         case Y5_OP_DETECT:
             if (field == 0) op.conv.x = v;
             else if (field == 1) op.dec.x_out = nv;
@@ -208,6 +223,7 @@ int run_op(const Op& op, hipStream_t s) {
         case Y5_OP_DECODE: return y5_launch_decode(op.dec, s);
         case Y5_OP_DECODE_MULTI: return y5_launch_decode_multi(op.decm, op.i[0], s);
         case Y5_OP_DETECT: return y5_launch_detect(op.conv, op.dec, op.i[0], s);
+        case Y5_OP_CONV_CHAIN: return y5_launch_conv_chain(op.conv, op.conv2, op.i[1], op.i[0], s);
     }
     return y5_fail(Y5_EINVAL, "plan: unknown op kind %d", op.kind);
 }
@@ -399,6 +415,28 @@ extern "C" int y5_plan_add_detect(y5_plan* p, const y5_conv_desc* conv, const y5
         op.flops = 2.0 * m * conv->cout * conv->cin;
         // read the feature map and the weights once, write z (and the permuted raw copy, when asked for) once, fp16
         op.bytes = 2.0 * (m * conv->cin + (double)conv->cout * conv->cin + (d->x_out ? 2.0 : 1.0) * m * outs);
+        p->ops.push_back(op);
+        return Y5_OK;
+    });
+}
+
+extern "C" int y5_plan_add_conv_chain(y5_plan* p, const y5_conv_desc* first, const y5_conv_desc* second, int keep_first, int variant) {
+    Y5_REQUIRE(p && first && second, "plan_add_conv_chain: null argument");
+    return guarded([&]() {
+        Op op;
+        op.kind = Y5_OP_CONV_CHAIN;
+        op.conv = *first;
+        op.conv2 = *second;
+        op.i[0] = variant;
+        op.i[1] = keep_first;
+        note_ptr(p, op, 0, first->x);
+        if (keep_first) note_ptr(p, op, 1, first->y);
+        note_ptr(p, op, 2, first->res);
+        note_ptr(p, op, 3, second->y);
+        const double m = (double)first->batch * first->ho * first->wo;
+        op.flops = 2.0 * m * first->cout * first->ksize * first->ksize * first->cin + 2.0 * m * second->cout * first->cout;
+        op.bytes = 2.0 * ((double)first->batch * first->h * first->w_in * first->cin + m * first->cout * ((first->res ? 1 : 0) + (keep_first ? 1 : 0)) +
+                          (double)first->cout * first->ksize * first->ksize * first->cin + m * second->cout + (double)second->cout * first->cout);
         p->ops.push_back(op);
         return Y5_OK;
     });

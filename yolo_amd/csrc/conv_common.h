@@ -41,6 +41,12 @@ struct ConvArgs {
     FastDiv div_tpi, div_tx;
     // loader-wave kernel, buffer addressing: bytes the x / w descriptors span
     int x_bytes, w_bytes;
+    // loader-wave kernel, chained 1x1 convolution on the finished tile (conv_lw.hip, TAIL)
+    const f16* w2;
+    const float *bias2, *scale2, *shift2;
+    f16* y2;
+    int w2_ld, y2_ld, Cout2, keep_first;
+    float slope2;
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

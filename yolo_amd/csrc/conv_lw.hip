@@ -48,8 +48,13 @@ struct LwCfg {
 // DETECT: the Detect head's 1x1 convolution with the box decode as its epilogue (models/yolo.py:32-46 in one kernel):
 // tiles are TP pixels of ONE image by all na*no channels, and instead of storing the NHWC tile the workgroup writes the
 // permuted raw copy x[i] and the decoded rows of z from it.
-template <int BM, int BN, int WM, int WN, int NL, int S, int BK, bool DIRECT, bool DETECT = false>
+// TAIL: a second, 1x1 stride-1 convolution on the finished tile (all of the first convolution's channels lie in the
+// tile: tiles_n = 1): out2 = post2(W2 . out1), with out1 = the first convolution's complete fp16 result including its
+// residual.  out1 goes to memory only if a.keep_first; the second GEMM reads it from LDS as its pixel operand and its
+// weights straight from global memory (they are L2-resident: every workgroup reads the same rows).
+template <int BM, int BN, int WM, int WN, int NL, int S, int BK, bool DIRECT, bool DETECT = false, bool TAIL = false>
 __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_lw_kernel(const ConvArgs a, const DecodeArgs dec) {
+    static_assert(!(DETECT && TAIL), "one special epilogue at a time");
     static_assert(!DETECT || (DIRECT && BM % TP == 0), "the decoding epilogue works on TP-pixel slices of a 1x1 convolution's tile");
     typedef LwCfg<BM, BN, WM, WN, NL, S, BK> Cfg;
     constexpr int NWC = WM * WN, NT = Cfg::NT;
@@ -85,6 +90,15 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_lw_kernel(const Conv
     float* prm = reinterpret_cast<float*>(smem + Cfg::PRM0);
     const EpiParams epi = epi_fetch(a, n0, t, BN);
     epi_store(prm, epi, t, BN);  // published by the barriers of the K loop
+    float* prm2 = prm + 3 * BN;  // TAIL: the second convolution's per-channel parameters (the launcher adds the space)
+    if constexpr (TAIL) {
+        if (t < BN) {
+            const bool in = t < a.Cout2;
+            prm2[t] = a.bias2 && in ? a.bias2[t] : 0.f;
+            prm2[BN + t] = a.scale2 && in ? a.scale2[t] : 1.f;
+            prm2[2 * BN + t] = a.scale2 && in ? a.shift2[t] : 0.f;
+        }
+    }
     const int nk = a.nk;
 
     if (wave >= NWC) {
@@ -210,7 +224,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_lw_kernel(const Conv
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int nl = wn * WTN + j * 32 + 8 * g + 4 * lh;
-                if (n0 + nl < a.Cout) {
+                if (TAIL || n0 + nl < a.Cout) {  // TAIL: columns past Cout are written too (zeros: zero weight rows)
 #pragma unroll
                     for (int i = 0; i < RM; ++i) {
                         const f32x4 v = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
@@ -234,12 +248,93 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_lw_kernel(const Conv
         }
         return;
     }
-    // ---- all waves: 16-byte stores of the finished tile (+ residual)
     constexpr int CPR = BN / 8;    // 16-byte chunks per tile row
     constexpr int RPP = NT / CPR;  // rows per pass
     static_assert(NT % CPR == 0, "whole rows per pass");
     const int cc = t % CPR, rr = t / CPR;
     const int n = n0 + cc * 8;
+    if constexpr (TAIL) {
+        // ---- A: the residual goes into the tile (and the first output to memory when it is kept)
+        if (a.res || a.keep_first) {
+            if (n < a.Cout) {
+#pragma unroll
+                for (int p = 0; p < (BM + RPP - 1) / RPP; ++p) {
+                    const int row = rr + p * RPP;
+                    const int m = m0 + row;
+                    if (row < BM && m < a.M) {
+                        f16x8 v = *reinterpret_cast<const f16x8*>(smem + row * EP + cc * 16);
+                        if (a.res) {
+                            v += *reinterpret_cast<const f16x8*>(a.res + (size_t)m * a.res_ld + n);
+                            *reinterpret_cast<f16x8*>(smem + row * EP + cc * 16) = v;
+                        }
+                        if (a.keep_first) *reinterpret_cast<f16x8*>(a.y + (size_t)m * a.y_ld + n) = v;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // ---- B: second GEMM, pixels x first-output channels from the tile, weights from global memory
+        const int wm = wave % WM, wn = wave / WM;
+        const int lr = lane & 31, lh = lane >> 5;
+        f32x16 acc2[RN][RM];
+        const bool mine = wave < NWC && wn * WTN < a.Cout2;  // wave-uniform: this wave owns second-output channels
+        if (mine) {
+#pragma unroll
+            for (int j = 0; j < RN; ++j)
+#pragma unroll
+                for (int i = 0; i < RM; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc2[j][i][e] = 0.f;
+            const int k2steps = (a.Cout + 15) / 16;  // the tile holds zeros from Cout up to BN
+#pragma unroll 2
+            for (int ks = 0; ks < k2steps; ++ks) {
+                const int k = ks * 16 + lh * 8;
+                f16x8 xf[RM], wf[RN];
+#pragma unroll
+                for (int j = 0; j < RN; ++j)
+                    wf[j] = *reinterpret_cast<const f16x8*>(a.w2 + (size_t)(wn * WTN + j * 32 + lr) * a.w2_ld + k);
+#pragma unroll
+                for (int i = 0; i < RM; ++i)
+                    xf[i] = *reinterpret_cast<const f16x8*>(smem + (wm * WTM + i * 32 + lr) * EP + k * 2);
+#pragma unroll
+                for (int j = 0; j < RN; ++j)
+#pragma unroll
+                    for (int i = 0; i < RM; ++i)
+                        acc2[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], xf[i], acc2[j][i], 0, 0, 0);
+            }
+        }
+        __syncthreads();  // every wave has read its rows of the first output
+        if (mine) {
+            const bool has_bias2 = a.bias2 != nullptr, has_scale2 = a.scale2 != nullptr;
+#pragma unroll
+            for (int j = 0; j < RN; ++j) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int nl = wn * WTN + j * 32 + 8 * g + 4 * lh;
+                    if (nl < a.Cout2) {
+#pragma unroll
+                        for (int i = 0; i < RM; ++i) {
+                            const f32x4 v = {acc2[j][i][4 * g], acc2[j][i][4 * g + 1], acc2[j][i][4 * g + 2], acc2[j][i][4 * g + 3]};
+                            const int ml = wm * WTM + i * 32 + lr;
+                            *reinterpret_cast<f16x4*>(smem + ml * EP + nl * 2) = post_op4_lds(v, nl, prm2, BN, has_bias2, has_scale2, a.slope2);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (n < a.Cout2) {
+#pragma unroll
+            for (int p = 0; p < (BM + RPP - 1) / RPP; ++p) {
+                const int row = rr + p * RPP;
+                const int m = m0 + row;
+                if (row < BM && m < a.M)
+                    *reinterpret_cast<f16x8*>(a.y2 + (size_t)m * a.y2_ld + n) = *reinterpret_cast<const f16x8*>(smem + row * EP + cc * 16);
+            }
+        }
+        return;
+    }
+    // ---- all waves: 16-byte stores of the finished tile (+ residual)
     if (n < a.Cout) {
 #pragma unroll
         for (int p = 0; p < (BM + RPP - 1) / RPP; ++p) {
@@ -255,7 +350,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_lw_kernel(const Conv
 }
 
 template <int BM, int BN, int WM, int WN, int NL, int S, int BK>
-int launch_lw(const ConvArgs& a0, bool direct, hipStream_t s) {
+int launch_lw(const ConvArgs& a0, bool direct, bool tail, hipStream_t s) {
     typedef LwCfg<BM, BN, WM, WN, NL, S, BK> Cfg;
     ConvArgs a = a0;
     const long long tiles_m = (a.M + BM - 1) / BM;
@@ -267,6 +362,7 @@ int launch_lw(const ConvArgs& a0, bool direct, hipStream_t s) {
     const long long total = tiles_m * a.tiles_n;
     if (total <= 0 || total > 0x7fffffffLL) return y5_fail(Y5_EINVAL, "conv: tile count %lld out of range", total);
     a.tiles_total = (int)total;
+    constexpr int SMEM_TAIL = Cfg::SMEM + 3 * BN * 4;  // + the second convolution's per-channel parameters
     static std::atomic<unsigned long long> attr_set{0};  // one bit per device: the attribute is per function and device
     const unsigned long long bit = 1ull << y5_current_device();
     if (!(attr_set.load() & bit)) {
@@ -274,10 +370,19 @@ int launch_lw(const ConvArgs& a0, bool direct, hipStream_t s) {
                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
         Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lw_kernel<BM, BN, WM, WN, NL, S, BK, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lw_kernel<BM, BN, WM, WN, NL, S, BK, false, false, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_TAIL));
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lw_kernel<BM, BN, WM, WN, NL, S, BK, true, false, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_TAIL));
         attr_set.fetch_or(bit);
     }
     const dim3 grid((unsigned)total), block(Cfg::NT);
-    if (direct)
+    if (tail && a.tiles_n != 1) return y5_fail(Y5_EINVAL, "conv chain: the first convolution's %d channels exceed the %d-channel tile", a.Cout, BN);
+    if (tail && direct)
+        hipLaunchKernelGGL((conv_lw_kernel<BM, BN, WM, WN, NL, S, BK, true, false, true>), grid, block, SMEM_TAIL, s, a, DecodeArgs{});
+    else if (tail)
+        hipLaunchKernelGGL((conv_lw_kernel<BM, BN, WM, WN, NL, S, BK, false, false, true>), grid, block, SMEM_TAIL, s, a, DecodeArgs{});
+    else if (direct)
         hipLaunchKernelGGL((conv_lw_kernel<BM, BN, WM, WN, NL, S, BK, true>), grid, block, Cfg::SMEM, s, a, DecodeArgs{});
     else
         hipLaunchKernelGGL((conv_lw_kernel<BM, BN, WM, WN, NL, S, BK, false>), grid, block, Cfg::SMEM, s, a, DecodeArgs{});
@@ -287,7 +392,7 @@ int launch_lw(const ConvArgs& a0, bool direct, hipStream_t s) {
 
 struct LwVariant {
     int bn, bk;
-    int (*launch)(const ConvArgs&, bool, hipStream_t);
+    int (*launch)(const ConvArgs&, bool, bool, hipStream_t);
 };
 #define Y5_LW(BM, BN, WM, WN, NL, S, BK) {BN, BK, &launch_lw<BM, BN, WM, WN, NL, S, BK>}
 const LwVariant kLw[] = {
@@ -369,14 +474,11 @@ int y5_launch_detect(const y5_conv_desc& c, const y5_decode_desc& d, int variant
 
 int y5_conv_lw_count() { return (int)(sizeof(kLw) / sizeof(kLw[0])); }
 
-// which = 1..y5_conv_lw_count().  Returns 0 when the shape is outside what this kernel family covers.
-int y5_try_conv_lw(const y5_conv_desc& d, hipStream_t s, int which, int* rc) {
-    if (which < 1 || which > y5_conv_lw_count()) return 0;
-    const LwVariant& v = kLw[which - 1];
-    const bool direct = d.ksize == 1 && d.stride == 1;
-    if (!direct && d.ksize != 3) return 0;
-    if ((long long)((d.cout + v.bn - 1) / v.bn) * v.bn > d.w_rows) return 0;
-    ConvArgs a{};
+namespace {
+// Kernel arguments of a convolution this family covers; false when it does not (addressing mode, tensor spans).
+bool fill_args(const y5_conv_desc& d, ConvArgs& a, bool* direct) {
+    *direct = d.ksize == 1 && d.stride == 1;
+    if (!*direct && d.ksize != 3) return false;
     a.x = static_cast<const f16*>(d.x);
     a.w = static_cast<const f16*>(d.w);
     a.bias = d.bias;
@@ -395,9 +497,66 @@ int y5_try_conv_lw(const y5_conv_desc& d, hipStream_t s, int which, int* rc) {
     a.div_cin = make_fastdiv((unsigned)d.cin);
     // spans the loaders may touch, for the buffer descriptors (32-bit offsets, sentinel 2^31 for zeros)
     const long long xb = (((long long)d.batch * d.h * d.w_in - 1) * d.x_ld + d.cin) * 2, wb = (long long)d.w_rows * d.kpad * 2;
-    if (xb >= 0x7fffffffLL || wb >= 0x7fffffffLL) return 0;
+    if (xb >= 0x7fffffffLL || wb >= 0x7fffffffLL) return false;
     a.x_bytes = (int)xb;
     a.w_bytes = (int)wb;
-    *rc = v.launch(a, direct, s);
+    return true;
+}
+}  // namespace
+
+// which = 1..y5_conv_lw_count().  Returns 0 when the shape is outside what this kernel family covers.
+int y5_try_conv_lw(const y5_conv_desc& d, hipStream_t s, int which, int* rc) {
+    if (which < 1 || which > y5_conv_lw_count()) return 0;
+    const LwVariant& v = kLw[which - 1];
+    if ((long long)((d.cout + v.bn - 1) / v.bn) * v.bn > d.w_rows) return 0;
+    ConvArgs a{};
+    bool direct = false;
+    if (!fill_args(d, a, &direct)) return 0;
+    *rc = v.launch(a, direct, false, s);
     return 1;
+}
+
+// A convolution followed by a 1x1 stride-1 convolution of its output, in one kernel (conv_lw_kernel, TAIL).
+// variant: 0 = the first tile shape that holds both channel counts, else 1..y5_conv_lw_count().
+int y5_launch_conv_chain(const y5_conv_desc& f, const y5_conv_desc& g, int keep_first, int variant, hipStream_t s) {
+    Y5_REQUIRE(variant >= 0 && variant <= y5_conv_lw_count(), "conv chain: variant %d out of range 0..%d", variant, y5_conv_lw_count());
+    Y5_REQUIRE(f.x && f.w && g.w && g.y && (f.y || !keep_first), "conv chain: null tensor pointer");
+    Y5_REQUIRE(f.ksize == 3 || (f.ksize == 1 && f.stride == 1), "conv chain: the first convolution is 3x3 or 1x1 stride 1");
+    Y5_REQUIRE(f.stride == 1 || f.stride == 2, "conv chain: stride %d not in {1,2}", f.stride);
+    Y5_REQUIRE(f.pad == f.ksize / 2 && f.batch > 0 && f.ho == (f.h + 2 * f.pad - f.ksize) / f.stride + 1 && f.wo == (f.w_in + 2 * f.pad - f.ksize) / f.stride + 1,
+               "conv chain: inconsistent geometry of the first convolution");
+    Y5_REQUIRE(f.cin > 0 && f.cin % 8 == 0 && f.x_ld % 8 == 0 && f.x_ld >= f.cin && f.cout > 0 && f.cout % 8 == 0, "conv chain: channel counts must be multiples of 8");
+    Y5_REQUIRE(!keep_first || (f.y_ld % 8 == 0 && f.y_ld >= f.cout), "conv chain: bad pitch of the first output");
+    Y5_REQUIRE(f.kpad % 64 == 0 && f.kpad >= f.ksize * f.ksize * f.cin && f.w_rows >= f.cout, "conv chain: first weights not packed");
+    Y5_REQUIRE(!f.scale || f.shift, "conv chain: scale without shift");
+    Y5_REQUIRE(!f.res || (f.res_ld % 8 == 0 && f.res_ld >= f.cout), "conv chain: bad residual pitch %d", f.res_ld);
+    Y5_REQUIRE(g.ksize == 1 && g.stride == 1 && g.pad == 0 && !g.res, "conv chain: the second convolution is 1x1 stride 1 without residual");
+    Y5_REQUIRE(g.batch == f.batch && g.h == f.ho && g.w_in == f.wo && g.ho == f.ho && g.wo == f.wo && g.cin == f.cout,
+               "conv chain: the second convolution must take the first one's output");
+    Y5_REQUIRE(g.cout > 0 && g.cout % 8 == 0 && g.y_ld % 8 == 0 && g.y_ld >= g.cout, "conv chain: cout %d / y_ld %d of the second convolution", g.cout, g.y_ld);
+    Y5_REQUIRE(g.kpad % 8 == 0 && g.kpad >= (f.cout + 15) / 16 * 16, "conv chain: second weights need kpad >= %d", (f.cout + 15) / 16 * 16);
+    Y5_REQUIRE(!g.scale || g.shift, "conv chain: scale without shift");
+    Y5_REQUIRE(y5_aligned16(f.x) && y5_aligned16(f.w) && y5_aligned16(f.y) && y5_aligned16(f.res) && y5_aligned16(g.w) && y5_aligned16(g.y),
+               "conv chain: pointers must be 16-byte aligned");
+    for (const y5_conv_desc* d : {&f, &g}) {
+        Y5_REQUIRE(d->act == Y5_ACT_NONE || (d->act == Y5_ACT_LEAKY && d->slope > 0.f && d->slope <= 1.f), "conv chain: bad activation");
+        Y5_REQUIRE(y5_aligned16(d->bias) && y5_aligned16(d->scale) && y5_aligned16(d->shift), "conv chain: per-channel vectors must be 16-byte aligned");
+    }
+    const int need = f.cout > g.cout ? f.cout : g.cout;
+    int which = variant;
+    if (which == 0)
+        for (int i = 1; i <= y5_conv_lw_count() && !which; ++i)
+            if (kLw[i - 1].bn >= need) which = i;
+    if (which == 0 || kLw[which - 1].bn < need) return y5_fail(Y5_EINVAL, "conv chain: no tile of variant %d holds %d channels", variant, need);
+    const LwVariant& v = kLw[which - 1];
+    Y5_REQUIRE(v.bn <= f.w_rows && v.bn <= g.w_rows, "conv chain: weights must be packed to at least %d rows", v.bn);
+    ConvArgs a{};
+    bool direct = false;
+    if (!fill_args(f, a, &direct)) return y5_fail(Y5_EINVAL, "conv chain: tensors of 2 GiB or more");
+    a.w2 = static_cast<const f16*>(g.w);
+    a.bias2 = g.bias; a.scale2 = g.scale; a.shift2 = g.shift;
+    a.y2 = static_cast<f16*>(g.y);
+    a.w2_ld = g.kpad; a.y2_ld = g.y_ld; a.Cout2 = g.cout; a.keep_first = keep_first;
+    a.slope2 = g.act == Y5_ACT_LEAKY ? g.slope : 1.f;
+    return v.launch(a, direct, true, s);
 }
