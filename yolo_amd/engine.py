@@ -25,6 +25,7 @@ from yolo_amd.utils.torch_utils import bn_affine
 
 _DISABLED = [0]
 _TUNED = {}   # conv shape key -> fastest variant id, shared by all plans of the process
+_TUNED_MS = {}  # key -> milliseconds per launch of the chosen variant
 
 
 class disabled:
@@ -115,7 +116,8 @@ class Act:
 
     @property
     def ptr(self):
-        return self.buf.data_ptr() + 2 * self.off
+        """Device address, or None for a shape-only tensor that is never materialised."""
+        return None if self.buf is None else self.buf.data_ptr() + 2 * self.off
 
     def slice(self, off, segs):
         return Act(self.buf, self.off + off, self.ld, self.batch, self.h, self.w, segs)
@@ -147,6 +149,7 @@ class Plan:
         self.batch, self.cin, self.h, self.w = x.shape
         self.keep = []          # tensors the plan's device pointers refer to
         self.labels = []        # one human-readable label per op
+        self._defer = None      # list collecting (label, descriptor, input) instead of recording, see _emit_conv
         self.homes = {}
         handle = C.c_void_p()
         _lib.check(self.lib.y5_plan_create(C.byref(handle)))
@@ -256,9 +259,54 @@ class Plan:
             self.labels.append('%s %sfocus+conv3x3 %d->%d @%dx%d' % (label, 'u8/255+' if image.dtype is torch.uint8 else '',
                                                                        x.c_log, out.c_log, ho, wo))
             return
+        text = '%s conv%dx%d s%d %d->%d @%dx%d' % (label, k, k, s, x.c_log, out.c_log, ho, wo)
+        if self._defer is not None:  # the caller combines the descriptors itself (_csp: chained convolutions)
+            self._defer.append((text, d, x))
+            return
         d.variant = self._tune(d, x)
         _lib.check(self.lib.y5_plan_add_conv(self.handle, C.byref(d)))
-        self.labels.append('%s conv%dx%d s%d %d->%d @%dx%d v%d' % (label, k, k, s, x.c_log, out.c_log, ho, wo, d.variant))
+        self.labels.append('%s v%d' % (text, d.variant))
+
+    def _emit_chain(self, defs):
+        """Record two deferred convolutions, the second a 1x1 of the first one's output that nothing else reads, either
+        as ONE kernel (y5_conv_chain_f16, the intermediate tensor is not written) or as two, whichever measures faster
+        on the real shapes."""
+        (t1, d1, x1), (t2, d2, x2) = defs
+        stream = _lib.current_stream()
+        tune = os.environ.get('Y5_AUTOTUNE', '1') != '0'
+        best, best_ms = 0, float('inf')
+        if self.lib.y5_conv_chain_f16(C.byref(d1), C.byref(d2), 0, 0, stream) == 0:
+            key = ('chain', d1.batch, d1.h, d1.w_in, d1.cin, d1.x_ld, d1.cout, d1.ksize, d1.stride, bool(d1.res), d2.cout, d2.y_ld)
+            if key not in _TUNED and tune:
+                x1.buf.uniform_(-1.0, 1.0)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                for v in range(1, self.lib.y5_conv_chain_num_variants() + 1):
+                    if self.lib.y5_conv_chain_f16(C.byref(d1), C.byref(d2), 0, v, stream) != 0:
+                        continue
+                    e0.record()
+                    for _ in range(4):
+                        self.lib.y5_conv_chain_f16(C.byref(d1), C.byref(d2), 0, v, stream)
+                    e1.record()
+                    e1.synchronize()
+                    if e0.elapsed_time(e1) / 4 < best_ms:
+                        best, best_ms = v, e0.elapsed_time(e1) / 4
+                _TUNED[key], _TUNED_MS[key] = best, best_ms
+            best, best_ms = _TUNED.get(key, 0), _TUNED_MS.get(key, 0.0 if not tune else float('inf'))
+        else:
+            best = -1
+        # the two-kernel alternative, each with its own fastest variant
+        d1.variant = self._tune(d1, x1)
+        ms1 = _TUNED_MS.get(self._last_key, float('inf'))
+        d2.variant = self._tune(d2, x2)
+        ms2 = _TUNED_MS.get(self._last_key, float('inf'))
+        if best >= 0 and (not tune or best_ms < ms1 + ms2):
+            _lib.check(self.lib.y5_plan_add_conv_chain(self.handle, C.byref(d1), C.byref(d2), 0, best))
+            self.labels.append('%s -> %s, one kernel v%d' % (t1, t2.split(' conv')[0], best))
+            return
+        _lib.check(self.lib.y5_plan_add_conv(self.handle, C.byref(d1)))
+        self.labels.append('%s v%d' % (t1, d1.variant))
+        _lib.check(self.lib.y5_plan_add_conv(self.handle, C.byref(d2)))
+        self.labels.append('%s v%d' % (t2, d2.variant))
 
     def _tune(self, d, x):
         """Pick the fastest compiled tile configuration for this convolution by timing every applicable one on
@@ -267,6 +315,7 @@ class Plan:
         if os.environ.get('Y5_AUTOTUNE', '1') == '0':
             return 0
         key = (d.batch, d.h, d.w_in, d.cin, d.x_ld, d.cout, d.y_ld, d.ksize, d.stride, bool(d.res), bool(d.bias), bool(d.scale))
+        self._last_key = key
         if key in _TUNED:
             return _TUNED[key]
         x.buf.uniform_(-1.0, 1.0)
@@ -286,6 +335,7 @@ class Plan:
             if t < best_t:
                 best, best_t = v, t
         _TUNED[key] = best
+        _TUNED_MS[key] = best_t / 4
         return best
 
     @staticmethod
@@ -581,11 +631,31 @@ class Plan:
             self._conv_block(name + '.cv1', m.cv1, x, t)
             cat = self._new_act(x.batch, x.h, x.w, [(c3, pad8(c3)), (c2, pad8(c2))])
             self._conv(name + '.cv2', x, m.cv2, cat.slice(pad8(c3), [(c2, pad8(c2))]), affine=(scale[c3:], shift[c3:]), act=m.act)
-        for bi, b in enumerate(m.m):
+        bots = list(m.m)
+        # The last Bottleneck's cv2 (+ residual) and cv3 as one kernel when both widths fit one tile: the Bottleneck's
+        # output, which only cv3 reads, is never written.
+        chain = (len(bots) > 0 and os.environ.get('Y5_CHAIN_FUSE', '1') != '0' and _conv_geometry(m.cv3) == (1, 1)
+                 and max(pad8(bots[-1].cv2.conv.out_channels), pad8(c3)) <= 256)
+        for bi, b in enumerate(bots[:-1] if chain else bots):
             nxt = self._new_act(x.batch, x.h, x.w, [(b.cv2.conv.out_channels, pad8(b.cv2.conv.out_channels))])
             self._bottleneck('%s.m%d' % (name, bi), b, t, nxt)
             t = nxt
-        self._conv(name + '.cv3', t, m.cv3, cat.slice(0, [(c3, pad8(c3))]), affine=(scale[:c3], shift[:c3]), act=m.act)
+        y1 = cat.slice(0, [(c3, pad8(c3))])
+        if chain:
+            b, bi = bots[-1], len(bots) - 1
+            cm = b.cv2.conv.out_channels
+            hidden = self._new_act(x.batch, x.h, x.w, [(b.cv1.conv.out_channels, pad8(b.cv1.conv.out_channels))])
+            self._conv_block('%s.m%d.cv1' % (name, bi), b.cv1, t, hidden)
+            nxt = self._new_act(x.batch, x.h, x.w, [(cm, pad8(cm))])  # written only if two kernels turn out faster
+            self._defer = []
+            try:
+                self._conv_block('%s.m%d.cv2' % (name, bi), b.cv2, hidden, nxt, res=t if b.add else None)
+                self._conv(name + '.cv3', nxt, m.cv3, y1, affine=(scale[:c3], shift[:c3]), act=m.act)
+            finally:
+                defs, self._defer = self._defer, None
+            self._emit_chain(defs)
+        else:
+            self._conv(name + '.cv3', t, m.cv3, y1, affine=(scale[:c3], shift[:c3]), act=m.act)
         self._conv_block(name + '.cv4', m.cv4, cat, out)
 
     def _spp(self, name, m, x, out):
