@@ -115,6 +115,14 @@ int y5_normalize_u8_f16(const void* x_u8, void* y_f16, int64_t n, y5_stream_t st
  * (utils/datasets.py:140-141 after .to(device)); results are bit-identical to normalising first. */
 int y5_focus_conv_u8(const y5_conv_desc* d, y5_stream_t stream);
 
+/* A first-layer 3x3 stride-1 pad-1 convolution straight from the 3-channel NCHW image, for the graphs that open with a
+ * plain Conv instead of Focus (models/yolov5s_ori.yaml layer 0; Conv.forward models/common.py:26 on the loader's image).
+ * Descriptor as for y5_focus_conv_f16 (x = image (batch, 3, h, w_in) NCHW, x_ld ignored, weights packed as for an
+ * 8-channel NHWC input: k = (r*3+q)*8 + c, kpad >= 72) with ho = h, wo = w_in and cout <= 64.  _u8: the uint8 image,
+ * divided by 255 on the way in like y5_focus_conv_u8. */
+int y5_stem_conv_f16(const y5_conv_desc* d, y5_stream_t stream);
+int y5_stem_conv_u8(const y5_conv_desc* d, y5_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Input packing: NCHW fp16 image batch -> NHWC fp16, optionally with the Focus space-to-depth
  * gather. Replaces: Focus.forward's four strided slices + cat  models/common.py:85-86
@@ -273,6 +281,8 @@ int y5_plan_bind_slot(y5_plan* p, int slot, const void* base, size_t bytes);
 int y5_plan_add_conv(y5_plan* p, const y5_conv_desc* d);
 int y5_plan_add_focus_conv(y5_plan* p, const y5_conv_desc* d);
 int y5_plan_add_focus_conv_u8(y5_plan* p, const y5_conv_desc* d);
+int y5_plan_add_stem_conv(y5_plan* p, const y5_conv_desc* d);
+int y5_plan_add_stem_conv_u8(y5_plan* p, const y5_conv_desc* d);
 int y5_plan_add_normalize_u8(y5_plan* p, const void* x_u8, void* y_f16, int64_t n);
 int y5_plan_add_pack_image(y5_plan* p, const void* x_nchw, void* y_nhwc, int batch, int c, int h, int w, int focus,
                            int y_ld);
@@ -315,6 +325,8 @@ int y5_plan_profile(y5_plan* p, void* const* ext, int n_ext, y5_stream_t stream,
 #define Y5_OP_NORMALIZE_U8 11
 #define Y5_OP_DETECT 12
 #define Y5_OP_CONV_CHAIN 13
+#define Y5_OP_STEM_CONV 14
+#define Y5_OP_STEM_CONV_U8 15
 int y5_plan_op_info(const y5_plan* p, int i, int* kind, double* flops, double* bytes);
 
 #ifdef __cplusplus

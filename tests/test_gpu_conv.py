@@ -392,3 +392,40 @@ def test_conv_chain_equals_two_convolutions(dev, shape):
                 assert not bool(torch.isnan(y2).any())
                 close(y2.permute(0, 3, 1, 2), y2_ref.permute(0, 3, 1, 2), rel=4e-3)
         assert taken >= 4
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 96, 32), (3, 41, 74, 16), (1, 130, 66, 56), (2, 8, 200, 13)], ids=lambda s: 'x'.join(map(str, s)))
+def test_stem_conv_from_the_nchw_image(dev, shape):
+    """y5_stem_conv_f16 / _u8 (first-layer 3x3 conv straight from the NCHW image) against torch's fp32 convolution with
+    the epilogue's rounding points, ragged image sizes and channel counts included."""
+    lib = _lib.lib()
+    B, H, W, Co = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    cop = (Co + 7) // 8 * 8
+    w = (torch.randn(Co, 3, 3, 3, generator=g) / 27 ** 0.5).half().to(dev)
+    wp = torch.zeros(256, 128, dtype=torch.float16, device=dev)
+    wv = torch.zeros(Co, 3, 3, 8, dtype=torch.float16, device=dev)
+    wv[..., :3] = w.permute(0, 2, 3, 1)
+    wp[:Co, :72] = wv.reshape(Co, 72)
+    scale = torch.zeros(cop, device=dev); shift = torch.zeros(cop, device=dev)
+    scale[:Co] = (torch.rand(Co, generator=g) + 0.5).to(dev); shift[:Co] = torch.randn(Co, generator=g).to(dev)
+    img8 = torch.randint(0, 256, (B, 3, H, W), generator=g, dtype=torch.int32).to(torch.uint8).to(dev)
+    for u8 in (False, True):
+        img = img8 if u8 else (torch.randn(B, 3, H, W, generator=g)).half().to(dev)
+        xh = (img.half() / 255.0) if u8 else img
+        y = torch.full((B, H, W, cop), float('nan'), dtype=torch.float16, device=dev)
+        d = _lib.ConvDesc()
+        d.x, d.w, d.y = img.data_ptr(), wp.data_ptr(), y.data_ptr()
+        d.scale, d.shift = scale.data_ptr(), shift.data_ptr()
+        d.batch, d.h, d.w_in, d.cin, d.x_ld = B, H, W, 3, 0
+        d.ho, d.wo, d.cout, d.y_ld = H, W, cop, cop
+        d.ksize, d.stride, d.pad, d.kpad, d.w_rows = 3, 1, 1, 128, 256
+        d.act, d.slope = _lib.ACT_LEAKY, 0.1
+        _lib.check((lib.y5_stem_conv_u8 if u8 else lib.y5_stem_conv_f16)(C.byref(d), _lib.current_stream()))
+        torch.cuda.synchronize()
+        acc = F.conv2d(xh.float(), w.float(), None, 1, 1)
+        ref = (acc.half().float() * scale[:Co].view(1, -1, 1, 1) + shift[:Co].view(1, -1, 1, 1)).half()
+        ref = F.leaky_relu(ref.float(), 0.1).half()
+        assert not bool(torch.isnan(y).any()), 'stem conv left output elements unwritten'
+        assert bool((y[..., Co:] == 0).all()), 'padding channels must be zero'
+        close(y[..., :Co].permute(0, 3, 1, 2), ref)

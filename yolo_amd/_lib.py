@@ -14,7 +14,7 @@ Y5_MAX_LEVELS = 4
 PLAN_SIDE, PLAN_JOIN = 1, 2
 ACT_NONE, ACT_LEAKY = 0, 1
 OK, EINVAL, EHIP, ENOMEM, EWORKSPACE = 0, -1, -2, -3, -4  # y5_status in include/y5hip.h
-OP_NAMES = {13: 'conv', 12: 'detect', 8: 'focus_conv', 9: 'decode', 10: 'focus_conv', 11: 'normalize', 1: 'conv', 2: 'pack', 3: 'maxpool', 4: 'upsample', 5: 'copy', 6: 'decode', 7: 'maxpool'}
+OP_NAMES = {14: 'focus_conv', 15: 'focus_conv', 13: 'conv', 12: 'detect', 8: 'focus_conv', 9: 'decode', 10: 'focus_conv', 11: 'normalize', 1: 'conv', 2: 'pack', 3: 'maxpool', 4: 'upsample', 5: 'copy', 6: 'decode', 7: 'maxpool'}
 
 
 class ConvDesc(C.Structure):
@@ -52,6 +52,8 @@ SIGNATURES = {
     'y5_conv_f16': (_i, [C.POINTER(ConvDesc), _s]),
     'y5_focus_conv_f16': (_i, [C.POINTER(ConvDesc), _s]),
     'y5_focus_conv_u8': (_i, [C.POINTER(ConvDesc), _s]),
+    'y5_stem_conv_f16': (_i, [C.POINTER(ConvDesc), _s]),
+    'y5_stem_conv_u8': (_i, [C.POINTER(ConvDesc), _s]),
     'y5_normalize_u8_f16': (_i, [C.c_void_p, C.c_void_p, C.c_int64, _s]),
     'y5_conv_num_variants': (_i, []),
     'y5_pack_image_f16': (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _s]),
@@ -78,6 +80,8 @@ SIGNATURES = {
     'y5_plan_add_conv': (_i, [_p, C.POINTER(ConvDesc)]),
     'y5_plan_add_focus_conv': (_i, [_p, C.POINTER(ConvDesc)]),
     'y5_plan_add_focus_conv_u8': (_i, [_p, C.POINTER(ConvDesc)]),
+    'y5_plan_add_stem_conv': (_i, [_p, C.POINTER(ConvDesc)]),
+    'y5_plan_add_stem_conv_u8': (_i, [_p, C.POINTER(ConvDesc)]),
     'y5_plan_add_normalize_u8': (_i, [_p, _p, _p, C.c_int64]),
     'y5_plan_add_pack_image': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i]),
     'y5_plan_add_maxpool': (_i, [_p, _p, _i, _p, _i, _i, _i, _i, _i, _i]),

@@ -48,6 +48,16 @@ extern "C" int y5_focus_conv_f16(const y5_conv_desc* d, y5_stream_t stream) {
 extern "C" int y5_sigmoid_f16(const void* x, void* y, int64_t n, int libm, y5_stream_t stream) {
     return y5_launch_sigmoid(x, y, n, libm, static_cast<hipStream_t>(stream));
 }
+extern "C" int y5_stem_conv_f16(const y5_conv_desc* d, y5_stream_t stream) {
+    Y5_REQUIRE(d, "stem_conv: null descriptor");
+    return y5_launch_stem_conv(*d, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int y5_stem_conv_u8(const y5_conv_desc* d, y5_stream_t stream) {
+    Y5_REQUIRE(d, "stem_conv_u8: null descriptor");
+    return y5_launch_stem_conv(*d, static_cast<hipStream_t>(stream), true);
+}
+
 extern "C" int y5_focus_conv_u8(const y5_conv_desc* d, y5_stream_t stream) {
     Y5_REQUIRE(d, "focus_conv_u8: null descriptor");
     return y5_launch_focus_conv(*d, static_cast<hipStream_t>(stream), true);
@@ -168,6 +178,8 @@ bool set_ptr(Op& op, int field, const void* v) {
         case Y5_OP_CONV:
         case Y5_OP_FOCUS_CONV:
         case Y5_OP_FOCUS_CONV_U8:
+        case Y5_OP_STEM_CONV:
+        case Y5_OP_STEM_CONV_U8:
             if (field == 0) op.conv.x = v;
             else if (field == 1) op.conv.y = nv;
             else if (field == 2) op.conv.res = v;
@@ -213,6 +225,8 @@ int run_op(const Op& op, hipStream_t s) {
         case Y5_OP_CONV: return y5_launch_conv(op.conv, s);
         case Y5_OP_FOCUS_CONV: return y5_launch_focus_conv(op.conv, s);
         case Y5_OP_FOCUS_CONV_U8: return y5_launch_focus_conv(op.conv, s, true);
+        case Y5_OP_STEM_CONV: return y5_launch_stem_conv(op.conv, s);
+        case Y5_OP_STEM_CONV_U8: return y5_launch_stem_conv(op.conv, s, true);
         case Y5_OP_NORMALIZE_U8: return y5_launch_normalize_u8(op.px, op.py, op.pixels, s);
         case Y5_OP_PACK: return y5_launch_pack_image(op.px, op.py, op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], s);
         case Y5_OP_MAXPOOL: return y5_launch_maxpool(op.px, op.i[0], op.py, op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6], s);
@@ -293,6 +307,8 @@ extern "C" int y5_plan_add_conv(y5_plan* p, const y5_conv_desc* d) {
 static int add_focus_conv(y5_plan* p, const y5_conv_desc* d, int kind);
 extern "C" int y5_plan_add_focus_conv(y5_plan* p, const y5_conv_desc* d) { return add_focus_conv(p, d, Y5_OP_FOCUS_CONV); }
 extern "C" int y5_plan_add_focus_conv_u8(y5_plan* p, const y5_conv_desc* d) { return add_focus_conv(p, d, Y5_OP_FOCUS_CONV_U8); }
+extern "C" int y5_plan_add_stem_conv(y5_plan* p, const y5_conv_desc* d) { return add_focus_conv(p, d, Y5_OP_STEM_CONV); }
+extern "C" int y5_plan_add_stem_conv_u8(y5_plan* p, const y5_conv_desc* d) { return add_focus_conv(p, d, Y5_OP_STEM_CONV_U8); }
 
 static int add_focus_conv(y5_plan* p, const y5_conv_desc* d, int kind) {
     Y5_REQUIRE(p && d, "plan_add_focus_conv: null argument");
@@ -303,9 +319,11 @@ static int add_focus_conv(y5_plan* p, const y5_conv_desc* d, int kind) {
         note_ptr(p, op, 0, d->x);
         note_ptr(p, op, 1, d->y);
         const double m = (double)d->batch * d->ho * d->wo;
-        op.flops = 2.0 * m * d->cout * 9 * 4 * d->cin;
-        op.bytes = (kind == Y5_OP_FOCUS_CONV_U8 ? 1.0 : 2.0) * d->batch * d->h * d->w_in * d->cin +
-                   2.0 * (m * d->cout + (double)d->cout * 9 * 4 * d->cin);
+        const bool stem = kind == Y5_OP_STEM_CONV || kind == Y5_OP_STEM_CONV_U8;
+        const bool u8 = kind == Y5_OP_FOCUS_CONV_U8 || kind == Y5_OP_STEM_CONV_U8;
+        const double taps = stem ? 9.0 : 9.0 * 4;  // Focus: 3x3 over the four space-to-depth copies of each channel
+        op.flops = 2.0 * m * d->cout * taps * d->cin;
+        op.bytes = (u8 ? 1.0 : 2.0) * d->batch * d->h * d->w_in * d->cin + 2.0 * (m * d->cout + (double)d->cout * taps * d->cin);
         p->ops.push_back(op);
         return Y5_OK;
     });

@@ -227,6 +227,169 @@ int launch_focus(const FocusArgs& a, hipStream_t s) {
     return Y5_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// First-layer 3x3 stride-1 convolution straight from the 3-channel NCHW image (the stem of the graphs without Focus,
+// models/yolov5s_ori.yaml layer 0): no packed NHWC copy of the image, whose 8-channel padding alone is 2.7x the image.
+// A workgroup (4 waves) owns 8 rows x 64 columns: the 10x66x3 patch goes to LDS once, each wave multiplies two rows.
+// K is ordered (c, r, q4) with q4 = the three taps of a row padded to four (zero weight): a k-group of 8 is then two
+// runs of 4 consecutive fp16 of patch rows, fetched as dwords and shifted by one halfword for odd columns.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kStemPW = 72;                    // halfs per patch row: 34 dwords used (image columns tx0-2 .. tx0+65), 2 zero
+constexpr int kStemPatch = 3 * 10 * kStemPW;   // halfs per patch buffer
+constexpr int kStemDw = 3 * 10 * 34;           // dwords staged per tile
+constexpr int kStemWP = 56;                    // halfs per weight row in LDS: 6 k-groups of 8 + 8 pad
+
+template <int RN, bool U8>
+__global__ __launch_bounds__(256) void stem_conv_kernel(const FocusArgs a) {
+    constexpr int CN = RN * 32;
+    constexpr int EROW = CN * 2 + 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f16* wl = reinterpret_cast<f16*>(smem);                                   // [CN][kStemWP]
+    uint32_t* patch = reinterpret_cast<uint32_t*>(smem + CN * kStemWP * 2);   // 2 x [3][10][kStemPW / 2]
+    unsigned char* scr = smem + CN * kStemWP * 2 + 2 * kStemPatch * 2;        // [4 waves][32][EROW]
+    float* prm = reinterpret_cast<float*>(scr + 4 * 32 * EROW);               // [3][CN]
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    for (int idx = t; idx < CN * 48; idx += 256) {
+        const int n = idx / 48, kk = idx - n * 48;
+        const int pr = 2 * (kk >> 3) + ((kk & 7) >> 2), q = kk & 3;  // pr = c*3 + r
+        const int c = pr / 3, r = pr - 3 * c;
+        f16 v = (f16)0.f;
+        if (pr < 9 && q < 3 && n < a.Cout) v = a.w[(size_t)n * a.w_ld + (r * 3 + q) * 8 + c];  // packed for 8 input channels
+        wl[n * kStemWP + kk] = v;
+    }
+    for (int i = t; i < kStemPatch; i += 256) patch[i] = 0u;  // both buffers (2 x kStemPatch halfs = kStemPatch dwords)
+    if (t < CN) {
+        const bool in = t < a.Cout;
+        prm[t] = a.bias && in ? a.bias[t] : 0.f;
+        prm[CN + t] = a.scale && in ? a.scale[t] : 1.f;
+        prm[2 * CN + t] = a.scale && in ? a.shift[t] : 0.f;
+    }
+    const bool has_bias = a.bias != nullptr, has_scale = a.scale != nullptr;
+    unsigned char* escr = scr + wave * 32 * EROW;
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    // pixel column x reads patch columns x+1 .. x+3 (patch column 0 is image column tx0-2): even x starts in the upper
+    // half of a dword
+    const unsigned sh = (unsigned)((lr & 1) ^ 1) * 16u;
+
+    // Patch staging, one tile ahead in registers: thread t owns dwords t, t+256, t+512, t+768 of the 1020 per tile.
+    int slot[4];      // dword index in a patch buffer, -1 beyond the tile
+    int srow[4], sdw[4], sch[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = t + 256 * i;
+        const int c = idx / 340, r2 = idx - c * 340;
+        const int r = r2 / 34, dwc = r2 - r * 34;
+        sch[i] = c; srow[i] = r; sdw[i] = dwc;
+        slot[i] = idx < kStemDw ? (c * 10 + r) * (kStemPW / 2) + dwc : -1;
+    }
+    uint32_t pre[4];
+    auto fetch = [&](int tile) {
+        const int b = tile / tiles_per_img, rem = tile - b * tiles_per_img;
+        const int ty0 = (rem / a.tiles_x) * 8, tx0 = (rem % a.tiles_x) * 64;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int iy = ty0 - 1 + srow[i], ix = tx0 - 2 + 2 * sdw[i];  // W is even: a dword is inside or outside as a whole
+            uint32_t v = 0u;
+            if (slot[i] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
+                const size_t off = ((size_t)(b * 3 + sch[i]) * a.H + iy) * a.W + ix;
+                if (U8) {  // two pixels, one byte each: img.half() / 255.0
+                    const unsigned short two = *reinterpret_cast<const unsigned short*>(static_cast<const unsigned char*>(a.img) + off);
+                    const f16 lo = (f16)((float)(two & 255u) / 255.0f), hi = (f16)((float)(two >> 8) / 255.0f);
+                    v = (uint32_t)__builtin_bit_cast(unsigned short, lo) | (uint32_t)__builtin_bit_cast(unsigned short, hi) << 16;
+                } else {
+                    v = *reinterpret_cast<const uint32_t*>(static_cast<const f16*>(a.img) + off);
+                }
+            }
+            pre[i] = v;
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (slot[i] >= 0) patch[buf * (kStemPatch / 2) + slot[i]] = pre[i];
+    };
+    const int first = blockIdx.x, stride = gridDim.x;
+    __syncthreads();  // zeroed patch buffers before the first stage
+    if (first < a.ntiles) {
+        fetch(first);
+        stage(0);
+        if (first + stride < a.ntiles) fetch(first + stride);
+    }
+    __syncthreads();
+    int cur = 0;
+
+    for (int tile = first; tile < a.ntiles; tile += stride) {
+        const int b = tile / tiles_per_img, rem = tile - b * tiles_per_img;
+        const int ty0 = (rem / a.tiles_x) * 8, tx0 = (rem % a.tiles_x) * 64;
+        const uint32_t* p32 = patch + cur * (kStemPatch / 2);
+
+        f32x16 acc[2][2][RN];  // [column half][row][channel tile]
+#pragma unroll
+        for (int xg = 0; xg < 2; ++xg)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int j = 0; j < RN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[xg][m][j][e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const int g = 2 * ks + lh;  // k-group of this half-wave
+            f16x8 wf[RN];
+#pragma unroll
+            for (int j = 0; j < RN; ++j) wf[j] = *reinterpret_cast<const f16x8*>(wl + (j * 32 + lr) * kStemWP + g * 8);
+#pragma unroll
+            for (int xg = 0; xg < 2; ++xg) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    u32x4 u;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        int pr = 2 * g + h;
+                        if (pr > 8) pr = 8;  // zero-weight groups: any valid address
+                        const int c = pr / 3, r = pr - 3 * c;
+                        const int hw = (c * 10 + 2 * wave + m + r) * kStemPW + 32 * xg + lr + 1;  // halfword of tap q = 0
+                        const uint32_t d0 = p32[hw >> 1], d1 = p32[(hw >> 1) + 1], d2 = p32[(hw >> 1) + 2];
+                        u[2 * h] = __builtin_amdgcn_alignbit(d1, d0, sh);
+                        u[2 * h + 1] = __builtin_amdgcn_alignbit(d2, d1, sh);
+                    }
+                    const f16x8 xf = __builtin_bit_cast(f16x8, u);
+#pragma unroll
+                    for (int j = 0; j < RN; ++j) acc[xg][m][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], xf, acc[xg][m][j], 0, 0, 0);
+                }
+            }
+        }
+        if (tile + stride < a.ntiles) {
+            stage(cur ^ 1);  // last read by the previous tile's products, which every wave finished before the barrier below
+            if (tile + 2 * stride < a.ntiles) fetch(tile + 2 * stride);
+        }
+#pragma unroll
+        for (int xg = 0; xg < 2; ++xg) {
+            if (has_bias && !has_scale) finish_tile<RN, true, false>(acc[xg], a, prm, escr, b, ty0 + 2 * wave, tx0 + 32 * xg, lane);
+            else if (!has_bias && has_scale) finish_tile<RN, false, true>(acc[xg], a, prm, escr, b, ty0 + 2 * wave, tx0 + 32 * xg, lane);
+            else if (has_bias) finish_tile<RN, true, true>(acc[xg], a, prm, escr, b, ty0 + 2 * wave, tx0 + 32 * xg, lane);
+            else finish_tile<RN, false, false>(acc[xg], a, prm, escr, b, ty0 + 2 * wave, tx0 + 32 * xg, lane);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+template <int RN, bool U8>
+int launch_stem(const FocusArgs& a, hipStream_t s) {
+    constexpr int CN = RN * 32;
+    constexpr size_t lds = (size_t)CN * kStemWP * 2 + 2 * kStemPatch * 2 + 4 * 32 * (CN * 2 + 16) + 3 * CN * 4;
+    const int grid = a.ntiles < 256 * 6 ? a.ntiles : 256 * 6;
+    hipLaunchKernelGGL((stem_conv_kernel<RN, U8>), dim3((unsigned)grid), dim3(256), lds, s, a);
+    Y5_LAUNCH_CHECK("stem_conv_kernel");
+    return Y5_OK;
+}
+
 }  // namespace
 
 int y5_launch_focus_conv(const y5_conv_desc& d, hipStream_t s, bool u8) {
@@ -262,4 +425,33 @@ int y5_launch_focus_conv(const y5_conv_desc& d, hipStream_t s, bool u8) {
     if (d.cout <= 32) return launch_focus<1, false>(a, s);
     if (d.cout <= 64) return launch_focus<2, false>(a, s);
     return launch_focus<3, false>(a, s);
+}
+
+int y5_launch_stem_conv(const y5_conv_desc& d, hipStream_t s, bool u8) {
+    Y5_REQUIRE(d.x && d.w && d.y, "stem_conv: null image, weight or output pointer");
+    Y5_REQUIRE(d.cin == 3, "stem_conv: the image must have 3 channels (got %d)", d.cin);
+    Y5_REQUIRE(d.ksize == 3 && d.stride == 1 && d.pad == 1, "stem_conv: 3x3 stride-1 pad-1 only");
+    Y5_REQUIRE(d.batch > 0 && d.h > 0 && d.w_in > 0 && d.ho == d.h && d.wo == d.w_in, "stem_conv: output must be %dx%d", d.h, d.w_in);
+    Y5_REQUIRE(d.w_in % 2 == 0, "stem_conv: the image width %d must be even (pixel pairs are staged)", d.w_in);
+    Y5_REQUIRE((long long)d.batch * 3 * d.h * d.w_in < 0x7fffffffLL, "stem_conv: image batch too large");
+    Y5_REQUIRE(d.cout > 0 && d.cout <= 64 && d.cout % 8 == 0, "stem_conv: cout %d must be a multiple of 8 up to 64", d.cout);
+    Y5_REQUIRE(d.y_ld >= d.cout && d.y_ld % 8 == 0, "stem_conv: y_ld %d must be a multiple of 8 >= cout", d.y_ld);
+    Y5_REQUIRE(d.kpad >= 72 && d.w_rows >= d.cout, "stem_conv: weights must be packed for 8 input channels (kpad >= 72)");
+    Y5_REQUIRE(!d.res, "stem_conv: no residual input");
+    Y5_REQUIRE((d.scale == nullptr) == (d.shift == nullptr), "stem_conv: scale and shift come together");
+    Y5_REQUIRE(d.act == Y5_ACT_NONE || (d.act == Y5_ACT_LEAKY && d.slope > 0.f && d.slope <= 1.f), "stem_conv: bad activation");
+    Y5_REQUIRE((reinterpret_cast<uintptr_t>(d.x) & (u8 ? 1u : 3u)) == 0 && y5_aligned16(d.y) && y5_aligned16(d.w), "stem_conv: misaligned pointer");
+    FocusArgs a{};
+    a.img = d.x;
+    a.w = static_cast<const f16*>(d.w);
+    a.bias = d.bias; a.scale = d.scale; a.shift = d.shift;
+    a.y = static_cast<f16*>(d.y);
+    a.B = d.batch; a.H = d.h; a.W = d.w_in; a.Ho = d.ho; a.Wo = d.wo; a.Cout = d.cout; a.y_ld = d.y_ld; a.w_ld = d.kpad;
+    a.tiles_x = (d.wo + 63) / 64; a.tiles_y = (d.ho + 7) / 8;
+    const long long nt = (long long)a.tiles_x * a.tiles_y * d.batch;
+    Y5_REQUIRE(nt < (1LL << 31), "stem_conv: too many tiles");
+    a.ntiles = (int)nt;
+    a.slope = d.act == Y5_ACT_LEAKY ? d.slope : 1.f;
+    if (u8) return d.cout <= 32 ? launch_stem<1, true>(a, s) : launch_stem<2, true>(a, s);
+    return d.cout <= 32 ? launch_stem<1, false>(a, s) : launch_stem<2, false>(a, s);
 }

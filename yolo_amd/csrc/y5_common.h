@@ -59,6 +59,7 @@ int y5_launch_conv_chain(const y5_conv_desc& f, const y5_conv_desc& g, int keep_
 int y5_conv_variant_count();
 // Focus gather + 3x3 convolution from the NCHW image (conv_focus.hip); d.x is the image, d.cin its 3 channels.
 int y5_launch_focus_conv(const y5_conv_desc& d, hipStream_t s, bool u8 = false);
+int y5_launch_stem_conv(const y5_conv_desc& d, hipStream_t s, bool u8 = false);
 int y5_launch_normalize_u8(const void* x, void* y, long long n, hipStream_t s);
 int y5_launch_pack_image(const void* x, void* y, int batch, int c, int h, int w, int focus, int y_ld, hipStream_t s);
 int y5_launch_maxpool(const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c, int k, hipStream_t s);

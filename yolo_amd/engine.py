@@ -215,7 +215,7 @@ class Plan:
         return packed, kpad, rows
 
     # ------------------------------------------------------------------ op emitters
-    def _emit_conv(self, label, x, weights, k, s, out, bias=None, scale=None, shift=None, slope=None, res=None, image=None):
+    def _emit_conv(self, label, x, weights, k, s, out, bias=None, scale=None, shift=None, slope=None, res=None, image=None, stem=False):
         """Record one convolution. weights: row groups [(tensor, padded rows)] matching out.segs; out: Act slice to
         write; bias/scale/shift: fp32 vectors of out.c_pad entries (or None); slope: LeakyReLU slope or None.
         image: the NCHW input batch when this is Focus's convolution read straight from it (x then only describes
@@ -254,10 +254,14 @@ class Plan:
             d.act, d.slope = _lib.ACT_LEAKY, slope
         if image is not None:
             d.batch, d.h, d.w_in, d.cin, d.x_ld = image.shape[0], image.shape[2], image.shape[3], image.shape[1], 0
-            add = self.lib.y5_plan_add_focus_conv_u8 if image.dtype is torch.uint8 else self.lib.y5_plan_add_focus_conv
+            u8 = image.dtype is torch.uint8
+            if stem:  # a plain first-layer conv on the image itself (x is the shape-only padded NHWC view of it)
+                add = self.lib.y5_plan_add_stem_conv_u8 if u8 else self.lib.y5_plan_add_stem_conv
+            else:
+                add = self.lib.y5_plan_add_focus_conv_u8 if u8 else self.lib.y5_plan_add_focus_conv
             _lib.check(add(self.handle, C.byref(d)))
-            self.labels.append('%s %sfocus+conv3x3 %d->%d @%dx%d' % (label, 'u8/255+' if image.dtype is torch.uint8 else '',
-                                                                       x.c_log, out.c_log, ho, wo))
+            self.labels.append('%s %s%sconv3x3 %d->%d @%dx%d' % (label, 'u8/255+' if u8 else '', 'image ' if stem else 'focus+',
+                                                                   x.c_log, out.c_log, ho, wo))
             return
         text = '%s conv%dx%d s%d %d->%d @%dx%d' % (label, k, k, s, x.c_log, out.c_log, ho, wo)
         if self._defer is not None:  # the caller combines the descriptors itself (_csp: chained convolutions)
@@ -346,23 +350,23 @@ class Plan:
             return float(act.negative_slope)
         raise Unsupported('activation %s' % type(act).__name__)
 
-    def _conv(self, label, x, conv, out, bias=None, affine=None, act=None, res=None, image=None):
+    def _conv(self, label, x, conv, out, bias=None, affine=None, act=None, res=None, image=None, stem=False):
         """One nn.Conv2d with optional bias, folded BatchNorm (scale, shift) and activation module."""
         k, s = _conv_geometry(conv)
         if len(out.segs) != 1:
             raise Unsupported('conv output slice mismatch')
         self._emit_conv(label, x, [(conv.weight, out.segs[0][1])], k, s, out, bias=bias,
                         scale=None if affine is None else affine[0], shift=None if affine is None else affine[1],
-                        slope=self._slope(act), res=res, image=image)
+                        slope=self._slope(act), res=res, image=image, stem=stem)
 
-    def _conv_block(self, label, m, x, out, res=None, image=None):
+    def _conv_block(self, label, m, x, out, res=None, image=None, stem=False):
         """A models.common.Conv (conv + BatchNorm + activation, or its fused form)."""
         if m.bn is None:
-            self._conv(label, x, m.conv, out, bias=m.conv.bias, act=m.act, res=res, image=image)
+            self._conv(label, x, m.conv, out, bias=m.conv.bias, act=m.act, res=res, image=image, stem=stem)
         else:
             if m.conv.bias is not None:
                 raise Unsupported('unfused Conv with conv bias')
-            self._conv(label, x, m.conv, out, affine=bn_affine(m.bn), act=m.act, res=res, image=image)
+            self._conv(label, x, m.conv, out, affine=bn_affine(m.bn), act=m.act, res=res, image=image, stem=stem)
 
     def _as_f16(self, image):
         """The NCHW input as fp16: itself, or for a uint8 input a buffer filled by a normalise op (x.half() / 255)."""
@@ -503,6 +507,14 @@ class Plan:
                 out = self._out_for(i, B, h, w, c_log)
                 self._focus(name, m, image, out)
             elif isinstance(m, common.Conv):
+                if (i == 0 and self.cin == 3 and _conv_geometry(m.conv) == (3, 1) and pad8(c_log) <= 64 and W % 2 == 0
+                        and os.environ.get('Y5_STEM_FUSE', '1') != '0'):
+                    # first-layer 3x3 conv straight from the NCHW (fp16 or uint8) image: no packed copy of the image
+                    shape_only = Act(None, 0, 8, B, H, W, [(3, 8)])
+                    out = self._out_for(i, B, h, w, c_log)
+                    self._conv_block(name, m, shape_only, out, image=image, stem=True)
+                    outs[i] = out
+                    continue
                 if i == 0:
                     xin = self._new_act(B, H, W, [(self.cin, pad8(self.cin))])
                     image = self._as_f16(image)
