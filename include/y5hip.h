@@ -156,6 +156,30 @@ int y5_upsample2x_f16(const void* x, int x_ld, void* y, int y_ld, int batch, int
  * Replaces: Concat.forward  models/common.py:95-96 for operands that cannot be produced in place. */
 int y5_copy_channels_f16(const void* x, int x_ld, void* y, int y_ld, int64_t pixels, int c, y5_stream_t stream);
 
+/* ----------------------------------------------------------------------------------------------
+ * Train-mode BatchNorm2d on NHWC fp16 tensors: the statistics-recalibration ("adaptive BN") forward.
+ * Replaces: the nn.BatchNorm2d calls of Conv.forward (models/common.py:27) and BottleneckCSP.forward
+ * (models/common.py:62) while the model is in train() mode under torch.no_grad(), as
+ * Training.adaptive_BN runs it (filter_pruning/fp_train.py:231-240): normalise with the batch's own mean and
+ * biased variance, move running_mean / running_var by `momentum` (running_var with the unbiased variance).
+ * A convolution's raw output is produced by y5_conv_f16 without post-ops; then, per BatchNorm:
+ *
+ * y5_bn_stats_f16:    sums[0..c) = per-channel sum, sums[c..2c) = per-channel sum of squares over `pixels`
+ *                     pixels (fp64, overwritten).  c a multiple of 8, <= 2048.
+ * y5_bn_finalize_f32: scale[i] = gamma[i] / sqrt(var_b[i] + eps), shift[i] = beta[i] - mean[i]*scale[i] for
+ *                     i < c_valid, 0 for the padding channels c_valid <= i < c; running statistics (fp32, may be
+ *                     NULL) updated in place.  gamma / beta may be NULL (1 / 0).  count = values per channel.
+ * y5_affine_act_f16:  y = fp16(act(x*scale[c] + shift[c]) + res), evaluated in fp32 and rounded once; act is
+ *                     Y5_ACT_NONE or Y5_ACT_LEAKY(slope); res may be NULL (Bottleneck's shortcut,
+ *                     models/common.py:43).  y may alias x.
+ * ---------------------------------------------------------------------------------------------- */
+int y5_bn_stats_f16(const void* x, int x_ld, int64_t pixels, int c, double* sums, y5_stream_t stream);
+int y5_bn_finalize_f32(const double* sums, int64_t count, int c, int c_valid, const float* gamma, const float* beta, float eps,
+                       float momentum, float* running_mean, float* running_var, float* scale, float* shift,
+                       y5_stream_t stream);
+int y5_affine_act_f16(const void* x, int x_ld, void* y, int y_ld, const void* res, int res_ld, int64_t pixels, int c,
+                      const float* scale, const float* shift, int act, float slope, y5_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Detect box decode for one pyramid level.
  * Replaces: Detect.forward  models/yolo.py:34-46 (view/permute/contiguous, sigmoid, grid/anchor

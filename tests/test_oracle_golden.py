@@ -100,3 +100,22 @@ def test_graph_parse_matches_reference_channel_plan(cfg):
             assert sum(1 for k in shapes if k.startswith(pre + '.m.') and k.endswith('cv1.conv.weight')) == L['repeat']
         elif L['type'] == 'Detect':
             assert [int(shapes['%s.m.%d.weight' % (pre, j)].split(';')[1]) for j in range(3)] == L['ch']
+
+
+@pytest.mark.parametrize('cfg', ['yolov5s', 'yolov5s_ori'])
+def test_adaptive_bn_statistics_match_reference(cfg):
+    """The train-mode forward of Training.adaptive_BN (filter_pruning/fp_train.py:231-240), two uint8 batches."""
+    z = util.golden('adaptive_bn_' + cfg)
+    model = util.build_model(cfg)
+    util.randomize_bn(model, 11)
+    cfgd = yaml.safe_load(open(os.path.join(util.CFG_DIR, cfg + '.yaml')))
+    before = model.state_dict()
+    after = y5ref.adaptive_bn(cfgd, before, [torch.from_numpy(z['x0']), torch.from_numpy(z['x1'])])
+    keys = [k for k in z.files if k.endswith('running_mean') or k.endswith('running_var')]
+    assert len(keys) == 2 * sum(1 for k in before if k.endswith('running_mean')) > 0
+    moved = 0
+    for k in keys:
+        assert torch.allclose(after[k], torch.from_numpy(z[k]), rtol=1e-5, atol=1e-6), k
+        moved += int(not torch.allclose(after[k], before[k].float()))
+    assert moved == len(keys)   # every BatchNorm saw the batches
+    assert int(z['num_batches_tracked']) == 1 + 2   # Model.__init__'s stride probe (models/yolo.py:76) is a train-mode forward too

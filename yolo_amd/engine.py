@@ -139,6 +139,33 @@ def _conv_geometry(conv):
     return k[0], s[0]
 
 
+def pack_conv_weight(weights, segs, device):
+    """Row groups [(weight (c, Cin_logical, k, k), padded rows)] -> fp16 [rows256][kpad64];
+    K index (r*k + q)*cin_pad + c following the input tensor's channel `segs`.  Returns (packed, kpad, rows)."""
+    k = weights[0][0].shape[-1]
+    cin_pad = sum(p for _, p in segs)
+    cin_log = sum(c for c, _ in segs)
+    total_rows = sum(p for _, p in weights)
+    rows = (total_rows + 255) // 256 * 256   # whole 256-row weight tiles for the widest kernel variant
+    kk = k * k * cin_pad
+    kpad = (kk + 63) // 64 * 64
+    packed = torch.zeros(rows, kpad, dtype=torch.float16, device=device)
+    r0 = 0
+    for weight, rpad in weights:
+        cout, cin = weight.shape[:2]
+        if cin != cin_log or weight.shape[-1] != k:
+            raise Unsupported('conv expects %d input channels, tensor has %d' % (cin, cin_log))
+        w = weight.detach().to(torch.float16).permute(0, 2, 3, 1)  # (Cout, k, k, Cin)
+        view = packed[r0:r0 + cout, :kk].view(cout, k, k, cin_pad)
+        src = dst = 0
+        for c, pc in segs:
+            view[..., dst:dst + c] = w[..., src:src + c]
+            src += c
+            dst += pc
+        r0 += rpad
+    return packed, kpad, rows
+
+
 class Plan:
     """A recorded launch plan for one (batch, height, width) plus the buffers it owns."""
 
@@ -188,29 +215,7 @@ class Plan:
         return out
 
     def _pack_weight(self, weights, segs):
-        """Row groups [(weight (c, Cin_logical, k, k), padded rows)] -> fp16 [rows256][kpad64];
-        K index (r*k + q)*cin_pad + c following the input tensor's channel `segs`."""
-        k = weights[0][0].shape[-1]
-        cin_pad = sum(p for _, p in segs)
-        cin_log = sum(c for c, _ in segs)
-        total_rows = sum(p for _, p in weights)
-        rows = (total_rows + 255) // 256 * 256   # whole 256-row weight tiles for the widest kernel variant
-        kk = k * k * cin_pad
-        kpad = (kk + 63) // 64 * 64
-        packed = torch.zeros(rows, kpad, dtype=torch.float16, device=self.device)
-        r0 = 0
-        for weight, rpad in weights:
-            cout, cin = weight.shape[:2]
-            if cin != cin_log or weight.shape[-1] != k:
-                raise Unsupported('conv expects %d input channels, tensor has %d' % (cin, cin_log))
-            w = weight.detach().to(torch.float16).permute(0, 2, 3, 1)  # (Cout, k, k, Cin)
-            view = packed[r0:r0 + cout, :kk].view(cout, k, k, cin_pad)
-            src = dst = 0
-            for c, pc in segs:
-                view[..., dst:dst + c] = w[..., src:src + c]
-                src += c
-                dst += pc
-            r0 += rpad
+        packed, kpad, rows = pack_conv_weight(weights, segs, self.device)
         self.keep.append(packed)
         return packed, kpad, rows
 
