@@ -164,18 +164,23 @@ int y5_copy_channels_f16(const void* x, int x_ld, void* y, int y_ld, int64_t pix
  * biased variance, move running_mean / running_var by `momentum` (running_var with the unbiased variance).
  * A convolution's raw output is produced by y5_conv_f16 without post-ops; then, per BatchNorm:
  *
- * y5_bn_stats_f16:    sums[0..c) = per-channel sum, sums[c..2c) = per-channel sum of squares over `pixels`
- *                     pixels (fp64, overwritten).  c a multiple of 8, <= 2048.
- * y5_bn_finalize_f32: scale[i] = gamma[i] / sqrt(var_b[i] + eps), shift[i] = beta[i] - mean[i]*scale[i] for
- *                     i < c_valid, 0 for the padding channels c_valid <= i < c; running statistics (fp32, may be
- *                     NULL) updated in place.  gamma / beta may be NULL (1 / 0).  count = values per channel.
+ * y5_bn_stats_rows:    number of rows R(pixels, c) of partial sums y5_bn_stats_f16 writes for such a tensor
+ *                     (<= 512; 0 for arguments y5_bn_stats_f16 rejects).
+ * y5_bn_stats_f16:    partials[r][0..c) = per-channel sums, partials[r][c..2c) = per-channel sums of squares of the
+ *                     r-th share of the `pixels` pixels, r < R (fp32, R*2c values, overwritten; no atomics, so
+ *                     repeated calls give identical bits).  c a multiple of 8, <= 2048.
+ * y5_bn_finalize_f32: adds the `rows` partial rows in fp64, then scale[i] = gamma[i] / sqrt(var_b[i] + eps),
+ *                     shift[i] = beta[i] - mean[i]*scale[i] for i < c_valid, 0 for the padding channels
+ *                     c_valid <= i < c; running statistics (fp32, may be NULL) updated in place.  gamma / beta may
+ *                     be NULL (1 / 0).  count = values per channel (= pixels).
  * y5_affine_act_f16:  y = fp16(act(x*scale[c] + shift[c]) + res), evaluated in fp32 and rounded once; act is
  *                     Y5_ACT_NONE or Y5_ACT_LEAKY(slope); res may be NULL (Bottleneck's shortcut,
  *                     models/common.py:43).  y may alias x.
  * ---------------------------------------------------------------------------------------------- */
-int y5_bn_stats_f16(const void* x, int x_ld, int64_t pixels, int c, double* sums, y5_stream_t stream);
-int y5_bn_finalize_f32(const double* sums, int64_t count, int c, int c_valid, const float* gamma, const float* beta, float eps,
-                       float momentum, float* running_mean, float* running_var, float* scale, float* shift,
+int y5_bn_stats_rows(int64_t pixels, int c);
+int y5_bn_stats_f16(const void* x, int x_ld, int64_t pixels, int c, float* partials, y5_stream_t stream);
+int y5_bn_finalize_f32(const float* partials, int rows, int64_t count, int c, int c_valid, const float* gamma, const float* beta,
+                       float eps, float momentum, float* running_mean, float* running_var, float* scale, float* shift,
                        y5_stream_t stream);
 int y5_affine_act_f16(const void* x, int x_ld, void* y, int y_ld, const void* res, int res_ld, int64_t pixels, int c,
                       const float* scale, const float* shift, int act, float slope, y5_stream_t stream);

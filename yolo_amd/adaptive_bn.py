@@ -53,7 +53,7 @@ class _BN:
             self.rm[self.idx] = bn.running_mean.detach().float()
             self.rv[self.idx] = bn.running_var.detach().float()
         self.scale, self.shift = z(), z()
-        self.sums = torch.zeros(2 * self.c_pad, dtype=torch.float64, device=device)
+        self.partials = {}   # pixels -> fp32 workspace of the per-workgroup partial sums
         self.tracked0 = int(bn.num_batches_tracked) if self.track and bn.num_batches_tracked is not None else 0
         self.batches = 0
 
@@ -145,16 +145,22 @@ class _Program:
         """Train-mode BatchNorm2d + optional LeakyReLU (+ residual) over tensor t, in place."""
         st = self.owner.bn_state(bn, t.segs)
         pixels = t.batch * t.h * t.w
-        self._call(label + ' bn stats', self.lib.y5_bn_stats_f16, t.ptr, t.ld, pixels, t.c_pad, st.sums.data_ptr())
-        self.ops.append((self._finalize, (st, pixels)))
+        rows = self.lib.y5_bn_stats_rows(pixels, t.c_pad)
+        if rows <= 0:
+            raise Unsupported('BatchNorm over %d channels' % t.c_pad)
+        part = st.partials.get(pixels)
+        if part is None:
+            part = st.partials[pixels] = torch.zeros(rows * 2 * t.c_pad, dtype=torch.float32, device=self.device)
+        self._call(label + ' bn stats', self.lib.y5_bn_stats_f16, t.ptr, t.ld, pixels, t.c_pad, part.data_ptr())
+        self.ops.append((self._finalize, (st, part, rows, pixels)))
         self.labels.append(label + ' bn finalize')
         act = _lib.ACT_NONE if slope is None else _lib.ACT_LEAKY
         self._call(label + ' bn apply', self.lib.y5_affine_act_f16, t.ptr, t.ld, t.ptr, t.ld, None if res is None else res.ptr,
                    0 if res is None else res.ld, pixels, t.c_pad, st.scale.data_ptr(), st.shift.data_ptr(), act,
                    0.0 if slope is None else slope)
 
-    def _finalize(self, st, pixels, stream):
-        rc = self.lib.y5_bn_finalize_f32(st.sums.data_ptr(), pixels, st.c_pad, st.c_pad, st.gamma.data_ptr(), st.beta.data_ptr(),
+    def _finalize(self, st, part, rows, pixels, stream):
+        rc = self.lib.y5_bn_finalize_f32(part.data_ptr(), rows, pixels, st.c_pad, st.c_pad, st.gamma.data_ptr(), st.beta.data_ptr(),
                                          float(st.bn.eps), st.momentum(), st.rm.data_ptr() if st.track else None,
                                          st.rv.data_ptr() if st.track else None, st.scale.data_ptr(), st.shift.data_ptr(), stream)
         st.batches += 1

@@ -82,14 +82,16 @@ extern "C" int y5_upsample2x_f16(const void* x, int x_ld, void* y, int y_ld, int
                                  y5_stream_t stream) {
     return y5_launch_upsample2x(x, x_ld, y, y_ld, batch, h, w, c, mode, static_cast<hipStream_t>(stream));
 }
-extern "C" int y5_bn_stats_f16(const void* x, int x_ld, int64_t pixels, int c, double* sums, y5_stream_t stream) {
-    return y5_launch_bn_stats(x, x_ld, pixels, c, sums, static_cast<hipStream_t>(stream));
+extern "C" int y5_bn_stats_rows(int64_t pixels, int c) { return y5_bn_stats_row_count(pixels, c); }
+
+extern "C" int y5_bn_stats_f16(const void* x, int x_ld, int64_t pixels, int c, float* partials, y5_stream_t stream) {
+    return y5_launch_bn_stats(x, x_ld, pixels, c, partials, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int y5_bn_finalize_f32(const double* sums, int64_t count, int c, int c_valid, const float* gamma, const float* beta,
-                                  float eps, float momentum, float* running_mean, float* running_var, float* scale, float* shift,
-                                  y5_stream_t stream) {
-    return y5_launch_bn_finalize(sums, count, c, c_valid, gamma, beta, eps, momentum, running_mean, running_var, scale, shift,
+extern "C" int y5_bn_finalize_f32(const float* partials, int rows, int64_t count, int c, int c_valid, const float* gamma,
+                                  const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* scale,
+                                  float* shift, y5_stream_t stream) {
+    return y5_launch_bn_finalize(partials, rows, count, c, c_valid, gamma, beta, eps, momentum, running_mean, running_var, scale, shift,
                                  static_cast<hipStream_t>(stream));
 }
 

@@ -13,14 +13,13 @@ constexpr int kThreads = 256;
 constexpr int kMaxC = 2048;
 
 // Thread t handles channel group t % G (8 channels, one 16-byte load) of pixels t / G, t / G + PL, ... of the
-// workgroup's pixel range, accumulating in fp32; partial sums meet in LDS (fp32) and leave the workgroup as one
-// fp64 atomic per channel and moment, so that the cross-workgroup order does not show in the result.
+// workgroup's pixel range, accumulating in fp32; the threads' partial sums meet in LDS (fp32) and leave the workgroup
+// as row blockIdx.x of `partials` ([rows][2C] fp32: C sums, then C sums of squares).  No global atomics: the rows are
+// added up in fp64 by bn_finalize, in a fixed order.
 __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const f16* __restrict__ x, int x_ld, long long pixels, int G,
-                                                            long long pix_per_wg, double* __restrict__ sums) {
-    __shared__ float part[2 * kMaxC];
+                                                            long long pix_per_wg, float* __restrict__ partials) {
+    __shared__ float part[kThreads * 16];  // [PL][2C]: every thread's 8 sums and 8 sums of squares
     const int C = G * 8;
-    for (int i = threadIdx.x; i < 2 * C; i += kThreads) part[i] = 0.f;
-    __syncthreads();
     const int PL = kThreads / G;  // pixels in flight per step (G <= kThreads)
     const int g = threadIdx.x % G, pl = threadIdx.x / G;
     if (pl < PL) {
@@ -38,31 +37,71 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const f16* __restric
                 q[e] = __builtin_fmaf(f, f, q[e]);
             }
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            atomicAdd(&part[g * 8 + e], s[e]);
-            atomicAdd(&part[C + g * 8 + e], q[e]);
-        }
+        float* mine = part + pl * 2 * C + g * 8;
+        *reinterpret_cast<f32x4*>(mine) = f32x4{s[0], s[1], s[2], s[3]};
+        *reinterpret_cast<f32x4*>(mine + 4) = f32x4{s[4], s[5], s[6], s[7]};
+        *reinterpret_cast<f32x4*>(mine + C) = f32x4{q[0], q[1], q[2], q[3]};
+        *reinterpret_cast<f32x4*>(mine + C + 4) = f32x4{q[4], q[5], q[6], q[7]};
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C; i += kThreads) atomicAdd(&sums[i], (double)part[i]);
+    // fixed summation order: the result does not depend on scheduling
+    float* row = partials + (size_t)blockIdx.x * 2 * C;
+    for (int i = threadIdx.x; i < 2 * C; i += kThreads) {
+        float a0 = 0.f, a1 = 0.f;
+        int j = 0;
+        for (; j + 1 < PL; j += 2) {
+            a0 += part[j * 2 * C + i];
+            a1 += part[(j + 1) * 2 * C + i];
+        }
+        if (j < PL) a0 += part[j * 2 * C + i];
+        row[i] = a0 + a1;
+    }
 }
 
-__global__ __launch_bounds__(kThreads) void bn_finalize_kernel(const double* __restrict__ sums, long long count, int C, int Cvalid,
-                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                               float eps, float momentum, float* __restrict__ running_mean,
-                                                               float* __restrict__ running_var, float* __restrict__ scale,
-                                                               float* __restrict__ shift) {
-    const int c = blockIdx.x * kThreads + threadIdx.x;
-    if (c >= C) return;
+// One workgroup per 8 channels: thread (ch = t % 8, rg = t / 8) adds rows rg, rg + 32, ... of its channel's two
+// columns in fp64, the 32 row groups meet in LDS, and the first 8 threads finish their channel.
+__global__ __launch_bounds__(kThreads) void bn_finalize_kernel(const float* __restrict__ partials, int rows, long long count, int C,
+                                                               int Cvalid, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps, float momentum,
+                                                               float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                               float* __restrict__ scale, float* __restrict__ shift) {
+    __shared__ double red[2][32][8];
+    const int ch = threadIdx.x & 7, rg = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + ch;
+    double s = 0.0, q = 0.0;
+    if (c < C) {
+        const float* col = partials + c;
+        int r = rg;
+        for (; r + 96 < rows; r += 128) {  // four independent loads in flight per column
+            const float s0 = col[(size_t)r * 2 * C], s1 = col[(size_t)(r + 32) * 2 * C], s2 = col[(size_t)(r + 64) * 2 * C],
+                        s3 = col[(size_t)(r + 96) * 2 * C];
+            const float q0 = col[(size_t)r * 2 * C + C], q1 = col[(size_t)(r + 32) * 2 * C + C], q2 = col[(size_t)(r + 64) * 2 * C + C],
+                        q3 = col[(size_t)(r + 96) * 2 * C + C];
+            s += ((double)s0 + (double)s1) + ((double)s2 + (double)s3);
+            q += ((double)q0 + (double)q1) + ((double)q2 + (double)q3);
+        }
+        for (; r < rows; r += 32) {
+            s += (double)col[(size_t)r * 2 * C];
+            q += (double)col[(size_t)r * 2 * C + C];
+        }
+    }
+    red[0][rg][ch] = s;
+    red[1][rg][ch] = q;
+    __syncthreads();
+    if (rg != 0 || c >= C) return;
+#pragma unroll
+    for (int i = 1; i < 32; ++i) {
+        s += red[0][i][ch];
+        q += red[1][i][ch];
+    }
     if (c >= Cvalid) {  // padding channels stay zero
         scale[c] = 0.f;
         shift[c] = 0.f;
         return;
     }
     const double n = (double)count;
-    const double mean = sums[c] / n;
-    double var = sums[C + c] / n - mean * mean;  // biased, what the normalisation uses
+    const double mean = s / n;
+    double var = q / n - mean * mean;  // biased, what the normalisation uses
     if (var < 0.0) var = 0.0;
     const double invstd = 1.0 / sqrt(var + (double)eps);
     const double ga = gamma ? (double)gamma[c] : 1.0, be = beta ? (double)beta[c] : 0.0;
@@ -108,36 +147,39 @@ __global__ __launch_bounds__(kThreads) void affine_act_kernel(const f16* __restr
 
 }  // namespace
 
-int y5_launch_bn_stats(const void* x, int x_ld, long long pixels, int c, double* sums, hipStream_t s) {
-    Y5_REQUIRE(x && sums, "bn_stats: null pointer");
+// Rows of partial sums y5_launch_bn_stats writes for this tensor: one per workgroup, each workgroup taking at least 16
+// steps of its PL pixels, at most 512 workgroups.
+int y5_bn_stats_row_count(long long pixels, int c) {
+    if (pixels <= 0 || c <= 0 || c % 8 != 0 || c > kMaxC) return 0;
+    const int PL = kThreads / (c / 8);
+    long long per_wg = 16LL * PL;
+    if ((pixels + per_wg - 1) / per_wg > 512) per_wg = (pixels + 511) / 512;
+    return (int)((pixels + per_wg - 1) / per_wg);
+}
+
+int y5_launch_bn_stats(const void* x, int x_ld, long long pixels, int c, float* partials, hipStream_t s) {
+    Y5_REQUIRE(x && partials, "bn_stats: null pointer");
     Y5_REQUIRE(c > 0 && c % 8 == 0 && c <= kMaxC && x_ld % 8 == 0 && x_ld >= c, "bn_stats: channels %d / pitch %d must be multiples of 8, channels <= %d", c, x_ld, kMaxC);
     Y5_REQUIRE(pixels > 0, "bn_stats: empty tensor");
-    Y5_REQUIRE(y5_aligned16(x) && (reinterpret_cast<uintptr_t>(sums) & 7) == 0, "bn_stats: misaligned pointer");
-    Y5_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * c, s));
-    const int G = c / 8;
-    // per-thread fp32 partials stay short (<= 64 values) on large tensors; at most 2048 workgroups
-    const int PL = kThreads / G;  // G <= kMaxC / 8 = kThreads
-    long long pix_per_wg = 64LL * PL;
-    long long grid = (pixels + pix_per_wg - 1) / pix_per_wg;
-    if (grid > 2048) {
-        grid = 2048;
-        pix_per_wg = (pixels + grid - 1) / grid;
-        grid = (pixels + pix_per_wg - 1) / pix_per_wg;
-    }
-    hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)grid), dim3(kThreads), 0, s, static_cast<const f16*>(x), x_ld, pixels, G,
-                       pix_per_wg, sums);
+    Y5_REQUIRE(y5_aligned16(x) && (reinterpret_cast<uintptr_t>(partials) & 3) == 0, "bn_stats: misaligned pointer");
+    const int rows = y5_bn_stats_row_count(pixels, c);
+    const long long per_wg = (pixels + rows - 1) / rows;
+    Y5_REQUIRE((long long)rows * per_wg >= pixels && (long long)(rows - 1) * per_wg < pixels, "bn_stats: internal row split");
+    hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)rows), dim3(kThreads), 0, s, static_cast<const f16*>(x), x_ld, pixels, c / 8,
+                       per_wg, partials);
     Y5_LAUNCH_CHECK("bn_stats_kernel");
     return Y5_OK;
 }
 
-int y5_launch_bn_finalize(const double* sums, long long count, int c, int c_valid, const float* gamma, const float* beta, float eps,
-                          float momentum, float* running_mean, float* running_var, float* scale, float* shift, hipStream_t s) {
-    Y5_REQUIRE(sums && scale && shift, "bn_finalize: null pointer");
+int y5_launch_bn_finalize(const float* partials, int rows, long long count, int c, int c_valid, const float* gamma, const float* beta,
+                          float eps, float momentum, float* running_mean, float* running_var, float* scale, float* shift,
+                          hipStream_t s) {
+    Y5_REQUIRE(partials && scale && shift, "bn_finalize: null pointer");
     Y5_REQUIRE(c > 0 && c_valid >= 0 && c_valid <= c, "bn_finalize: %d valid of %d channels", c_valid, c);
-    Y5_REQUIRE(count > 0, "bn_finalize: no values");
+    Y5_REQUIRE(count > 0 && rows > 0, "bn_finalize: no values");
     Y5_REQUIRE(eps >= 0.f && momentum >= 0.f && momentum <= 1.f, "bn_finalize: eps %g / momentum %g out of range", eps, momentum);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + kThreads - 1) / kThreads), dim3(kThreads), 0, s, sums, count, c, c_valid, gamma,
-                       beta, eps, momentum, running_mean, running_var, scale, shift);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 7) / 8), dim3(kThreads), 0, s, partials, rows, count, c, c_valid, gamma, beta,
+                       eps, momentum, running_mean, running_var, scale, shift);
     Y5_LAUNCH_CHECK("bn_finalize_kernel");
     return Y5_OK;
 }

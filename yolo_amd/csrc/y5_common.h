@@ -71,8 +71,10 @@ int y5_launch_copy_channels(const void* x, int x_ld, void* y, int y_ld, int64_t 
 int y5_launch_decode(const y5_decode_desc& d, hipStream_t s);
 int y5_launch_decode_multi(const y5_decode_desc* d, int n, hipStream_t s);
 int y5_launch_sigmoid(const void* x, void* y, long long n, int libm, hipStream_t s);
-int y5_launch_bn_stats(const void* x, int x_ld, long long pixels, int c, double* sums, hipStream_t s);
-int y5_launch_bn_finalize(const double* sums, long long count, int c, int c_valid, const float* gamma, const float* beta, float eps,
-                          float momentum, float* running_mean, float* running_var, float* scale, float* shift, hipStream_t s);
+int y5_bn_stats_row_count(long long pixels, int c);
+int y5_launch_bn_stats(const void* x, int x_ld, long long pixels, int c, float* partials, hipStream_t s);
+int y5_launch_bn_finalize(const float* partials, int rows, long long count, int c, int c_valid, const float* gamma, const float* beta,
+                          float eps, float momentum, float* running_mean, float* running_var, float* scale, float* shift,
+                          hipStream_t s);
 int y5_launch_affine_act(const void* x, int x_ld, void* y, int y_ld, const void* res, int res_ld, long long pixels, int c,
                          const float* scale, const float* shift, int act, float slope, hipStream_t s);
