@@ -79,6 +79,16 @@ def main():
                     tot[kind] = tot.get(kind, 0.0) + us
                     print('%3d %9.1f us  %s' % (i, us, label))
         print('by kind (us):', {k: round(v, 1) for k, v in tot.items()}, 'sum', round(sum(tot.values()), 1))
+        # bytes the BatchNorm kernels must move: stats read every normalised tensor once, apply reads and writes it
+        # (and reads the shortcut where there is one)
+        nbytes = {'bn stats': 0, 'bn apply': 0}
+        for (fn, args), label in zip(prog.ops, prog.labels):
+            if label.endswith('bn stats'):
+                nbytes['bn stats'] += args[2] * args[3] * 2
+            elif label.endswith('bn apply'):
+                nbytes['bn apply'] += args[6] * args[7] * 2 * (3 if args[4] else 2)
+        for k, b in nbytes.items():
+            print('%s: %.3f GB algorithmic, %.0f GB/s' % (k, b / 1e9, b / 1e3 / tot[k]))
 
 
 if __name__ == '__main__':

@@ -28,8 +28,23 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const f16* __restric
         float s[8], q[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
-        for (long long p = p0 + pl; p < p1; p += PL) {
-            const f16x8 v = *reinterpret_cast<const f16x8*>(x + p * x_ld + g * 8);
+        const f16* xg = x + g * 8;
+        long long p = p0 + pl;
+        for (; p + 3LL * PL < p1; p += 4LL * PL) {  // four loads in flight
+            f16x8 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f16x8*>(xg + (p + (long long)u * PL) * x_ld);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = (float)v[u][e];
+                    s[e] += f;
+                    q[e] = __builtin_fmaf(f, f, q[e]);
+                }
+        }
+        for (; p < p1; p += PL) {
+            const f16x8 v = *reinterpret_cast<const f16x8*>(xg + p * x_ld);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float f = (float)v[e];
@@ -127,21 +142,36 @@ __global__ __launch_bounds__(kThreads) void affine_act_kernel(const f16* __restr
     }
     __syncthreads();
     const long long total = pixels * C8;
-    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long long)gridDim.x * kThreads) {
-        const int c8 = (int)(i % C8);
-        const long long p = i / C8;
-        const f16x8 v = *reinterpret_cast<const f16x8*>(x + p * x_ld + c8 * 8);
-        f16x8 r;
-        if (RES) r = *reinterpret_cast<const f16x8*>(res + p * res_ld + c8 * 8);
-        f16x8 o;
+    const long long step = (long long)gridDim.x * kThreads;
+    for (long long i0 = (long long)blockIdx.x * kThreads + threadIdx.x; i0 < total; i0 += 2 * step) {
+        f16x8 v[2], r[2];
+        long long p[2];
+        int c8[2];
+        bool on[2];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float f = __builtin_fmaf((float)v[e], prm[c8 * 8 + e], prm[C + c8 * 8 + e]);
-            if (LEAKY) f = f > 0.f ? f : f * slope;
-            if (RES) f += (float)r[e];
-            o[e] = (f16)f;
+        for (int u = 0; u < 2; ++u) {  // both loads issued before either is used
+            const long long i = i0 + u * step;
+            on[u] = i < total;
+            c8[u] = (int)(i % C8);
+            p[u] = i / C8;
+            if (on[u]) {
+                v[u] = *reinterpret_cast<const f16x8*>(x + p[u] * x_ld + c8[u] * 8);
+                if (RES) r[u] = *reinterpret_cast<const f16x8*>(res + p[u] * res_ld + c8[u] * 8);
+            }
         }
-        *reinterpret_cast<f16x8*>(y + p * y_ld + c8 * 8) = o;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!on[u]) continue;
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = __builtin_fmaf((float)v[u][e], prm[c8[u] * 8 + e], prm[C + c8[u] * 8 + e]);
+                if (LEAKY) f = f > 0.f ? f : f * slope;
+                if (RES) f += (float)r[u][e];
+                o[e] = (f16)f;
+            }
+            *reinterpret_cast<f16x8*>(y + p[u] * y_ld + c8[u] * 8) = o;
+        }
     }
 }
 
@@ -193,8 +223,8 @@ int y5_launch_affine_act(const void* x, int x_ld, void* y, int y_ld, const void*
     Y5_REQUIRE(act == Y5_ACT_NONE || act == Y5_ACT_LEAKY, "affine_act: activation %d", act);
     Y5_REQUIRE(y5_aligned16(x) && y5_aligned16(y) && y5_aligned16(res), "affine_act: pointers must be 16-byte aligned");
     const long long total = pixels * (c / 8);
-    long long blocks = (total + kThreads - 1) / kThreads;
-    if (blocks > 256LL * 16) blocks = 256LL * 16;
+    long long blocks = (total + 2 * kThreads - 1) / (2 * kThreads);
+    if (blocks > 256LL * 8) blocks = 256LL * 8;
     const dim3 grid((unsigned)blocks), block(kThreads);
     const f16 *xp = static_cast<const f16*>(x), *rp = static_cast<const f16*>(res);
     f16* yp = static_cast<f16*>(y);
