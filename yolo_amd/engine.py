@@ -276,25 +276,25 @@ class Plan:
         _lib.check(self.lib.y5_plan_add_conv(self.handle, C.byref(d)))
         self.labels.append('%s v%d' % (text, d.variant))
 
-    def _emit_chain(self, defs):
-        """Record two deferred convolutions, the second a 1x1 of the first one's output that nothing else reads, either
-        as ONE kernel (y5_conv_chain_f16, the intermediate tensor is not written) or as two, whichever measures faster
-        on the real shapes."""
+    def _emit_chain(self, defs, keep_first=0):
+        """Record two deferred convolutions, the second a 1x1 of the first one's output, either as ONE kernel
+        (y5_conv_chain_f16; with keep_first = 0 the intermediate tensor, which nothing else reads, is not written) or as
+        two, whichever measures faster on the real shapes."""
         (t1, d1, x1), (t2, d2, x2) = defs
         stream = _lib.current_stream()
         tune = os.environ.get('Y5_AUTOTUNE', '1') != '0'
         best, best_ms = 0, float('inf')
-        if self.lib.y5_conv_chain_f16(C.byref(d1), C.byref(d2), 0, 0, stream) == 0:
-            key = ('chain', d1.batch, d1.h, d1.w_in, d1.cin, d1.x_ld, d1.cout, d1.ksize, d1.stride, bool(d1.res), d2.cout, d2.y_ld)
+        if self.lib.y5_conv_chain_f16(C.byref(d1), C.byref(d2), keep_first, 0, stream) == 0:
+            key = ('chain', keep_first, d1.batch, d1.h, d1.w_in, d1.cin, d1.x_ld, d1.cout, d1.ksize, d1.stride, bool(d1.res), d2.cout, d2.y_ld)
             if key not in _TUNED and tune:
                 x1.buf.uniform_(-1.0, 1.0)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 for v in range(1, self.lib.y5_conv_chain_num_variants() + 1):
-                    if self.lib.y5_conv_chain_f16(C.byref(d1), C.byref(d2), 0, v, stream) != 0:
+                    if self.lib.y5_conv_chain_f16(C.byref(d1), C.byref(d2), keep_first, v, stream) != 0:
                         continue
                     e0.record()
                     for _ in range(4):
-                        self.lib.y5_conv_chain_f16(C.byref(d1), C.byref(d2), 0, v, stream)
+                        self.lib.y5_conv_chain_f16(C.byref(d1), C.byref(d2), keep_first, v, stream)
                     e1.record()
                     e1.synchronize()
                     if e0.elapsed_time(e1) / 4 < best_ms:
@@ -309,7 +309,7 @@ class Plan:
         d2.variant = self._tune(d2, x2)
         ms2 = _TUNED_MS.get(self._last_key, float('inf'))
         if best >= 0 and (not tune or best_ms < ms1 + ms2):
-            _lib.check(self.lib.y5_plan_add_conv_chain(self.handle, C.byref(d1), C.byref(d2), 0, best))
+            _lib.check(self.lib.y5_plan_add_conv_chain(self.handle, C.byref(d1), C.byref(d2), keep_first, best))
             self.labels.append('%s -> %s, one kernel v%d' % (t1, t2.split(' conv')[0], best))
             return
         _lib.check(self.lib.y5_plan_add_conv(self.handle, C.byref(d1)))
@@ -653,16 +653,36 @@ class Plan:
         # output, which only cv3 reads, is never written.
         chain = (len(bots) > 0 and os.environ.get('Y5_CHAIN_FUSE', '1') != '0' and _conv_geometry(m.cv3) == (1, 1)
                  and max(pad8(bots[-1].cv2.conv.out_channels), pad8(c3)) <= 256)
+        # Between Bottlenecks the same kernel serves m[i].cv2 (+ residual) -> m[i+1].cv1 with the first result kept (the
+        # next shortcut needs it): the 1x1 then reads its input from LDS instead of HBM.  Measured per shape like the rest.
+        link = chain and os.environ.get('Y5_CHAIN_LINK', '1') != '0'
+        hidden = None
         for bi, b in enumerate(bots[:-1] if chain else bots):
             nxt = self._new_act(x.batch, x.h, x.w, [(b.cv2.conv.out_channels, pad8(b.cv2.conv.out_channels))])
-            self._bottleneck('%s.m%d' % (name, bi), b, t, nxt)
-            t = nxt
+            if not link:
+                self._bottleneck('%s.m%d' % (name, bi), b, t, nxt)
+                t = nxt
+                continue
+            if hidden is None:
+                hidden = self._new_act(x.batch, x.h, x.w, [(b.cv1.conv.out_channels, pad8(b.cv1.conv.out_channels))])
+                self._conv_block('%s.m%d.cv1' % (name, bi), b.cv1, t, hidden)
+            nb = bots[bi + 1]
+            nhidden = self._new_act(x.batch, x.h, x.w, [(nb.cv1.conv.out_channels, pad8(nb.cv1.conv.out_channels))])
+            self._defer = []
+            try:
+                self._conv_block('%s.m%d.cv2' % (name, bi), b.cv2, hidden, nxt, res=t if b.add else None)
+                self._conv_block('%s.m%d.cv1' % (name, bi + 1), nb.cv1, nxt, nhidden)
+            finally:
+                defs, self._defer = self._defer, None
+            self._emit_chain(defs, keep_first=1)
+            t, hidden = nxt, nhidden
         y1 = cat.slice(0, [(c3, pad8(c3))])
         if chain:
             b, bi = bots[-1], len(bots) - 1
             cm = b.cv2.conv.out_channels
-            hidden = self._new_act(x.batch, x.h, x.w, [(b.cv1.conv.out_channels, pad8(b.cv1.conv.out_channels))])
-            self._conv_block('%s.m%d.cv1' % (name, bi), b.cv1, t, hidden)
+            if hidden is None:
+                hidden = self._new_act(x.batch, x.h, x.w, [(b.cv1.conv.out_channels, pad8(b.cv1.conv.out_channels))])
+                self._conv_block('%s.m%d.cv1' % (name, bi), b.cv1, t, hidden)
             nxt = self._new_act(x.batch, x.h, x.w, [(cm, pad8(cm))])  # written only if two kernels turn out faster
             self._defer = []
             try:
