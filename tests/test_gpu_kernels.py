@@ -49,6 +49,20 @@ def test_maxpool_and_cascade(dev, k):
         assert torch.equal(cat.permute(0, 3, 1, 2), ref)
 
 
+@pytest.mark.parametrize('c,h,w,levels,k', [(32, 20, 20, 3, 5), (24, 20, 14, 3, 5), (16, 33, 40, 2, 3), (8, 45, 45, 3, 5),
+                                            (256, 20, 20, 3, 5), (16, 7, 5, 4, 3)])
+def test_maxpool_cascade_shapes(dev, c, h, w, levels, k):
+    """Two vectors per workgroup (c % 16 == 0), one vector, and planes too large for the three-plane kernels."""
+    lib = _lib.lib()
+    x = torch.randn(2, c, h, w, generator=torch.Generator().manual_seed(c + h)).half().to(dev)
+    ld = (levels + 1) * c
+    cat = torch.zeros(2, h, w, ld, dtype=torch.float16, device=dev)
+    cat[..., :c] = x.permute(0, 2, 3, 1)
+    _lib.check(lib.y5_maxpool_cascade_f16(cat.data_ptr(), ld, cat.data_ptr() + 2 * c, ld, c, levels, 2, h, w, c, k, _lib.current_stream()))
+    ref = torch.cat([x] + [F.max_pool2d(x, kk, 1, kk // 2) for kk in [l * (k - 1) + k for l in range(levels)]], 1)
+    assert torch.equal(cat.permute(0, 3, 1, 2), ref)
+
+
 @pytest.mark.parametrize('mode', ['nearest', 'bilinear'])
 def test_upsample_into_concat_slice(dev, mode):
     lib = _lib.lib()

@@ -165,6 +165,48 @@ __global__ __launch_bounds__(kThreads) void maxpool_cascade_kernel(const f16* __
     }
 }
 
+// The same cascade, separable (a k x k max is a row max of column maxes) and VG 8-channel vectors wide: a workgroup
+// owns one image and VG adjacent vectors, so that global accesses are VG*16 contiguous bytes per pixel, and every
+// level costs 2k LDS reads per output instead of k*k.  Three LDS planes rotate: level input, row maxes, level output.
+template <int VG>
+__global__ __launch_bounds__(kThreads) void maxpool_cascade_sep_kernel(const f16* __restrict__ x, int x_ld, f16* __restrict__ y,
+                                                                       int y_ld, int y_step, int levels, int H, int W, int CG, int k) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int npix = H * W, n = npix * VG, r = k / 2;
+    f16x8* src = reinterpret_cast<f16x8*>(smem_raw);
+    f16x8* tmp = src + n;
+    f16x8* dst = tmp + n;
+    const int b = blockIdx.x / CG, c0 = (blockIdx.x - b * CG) * VG * 8;
+    const long long pbase = (long long)b * npix;
+    for (int i = threadIdx.x; i < n; i += kThreads) {
+        const int p = i / VG, v = i - p * VG;
+        src[i] = *reinterpret_cast<const f16x8*>(x + (pbase + p) * x_ld + c0 + v * 8);
+    }
+    __syncthreads();
+    for (int l = 0; l < levels; ++l) {
+        for (int i = threadIdx.x; i < n; i += kThreads) {  // along the row
+            const int p = i / VG, v = i - p * VG;
+            const int py = p / W, px = p - py * W;
+            const int x0 = px - r < 0 ? 0 : px - r, x1 = px + r >= W ? W - 1 : px + r;
+            f16x8 m = src[(py * W + x0) * VG + v];
+            for (int xx = x0 + 1; xx <= x1; ++xx) m = __builtin_elementwise_max(m, src[(py * W + xx) * VG + v]);
+            tmp[i] = m;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += kThreads) {  // along the column
+            const int p = i / VG, v = i - p * VG;
+            const int py = p / W, px = p - py * W;
+            const int y0 = py - r < 0 ? 0 : py - r, y1 = py + r >= H ? H - 1 : py + r;
+            f16x8 m = tmp[(y0 * W + px) * VG + v];
+            for (int yy = y0 + 1; yy <= y1; ++yy) m = __builtin_elementwise_max(m, tmp[(yy * W + px) * VG + v]);
+            dst[i] = m;
+            *reinterpret_cast<f16x8*>(y + (pbase + p) * y_ld + (long long)l * y_step + c0 + v * 8) = m;
+        }
+        __syncthreads();
+        f16x8* t = src; src = dst; dst = t;
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void copy_channels_kernel(const f16* __restrict__ x, int x_ld, f16* __restrict__ y, int y_ld,
                                                                  long long pixels, int C8) {
     const long long total = pixels * C8;
@@ -247,6 +289,21 @@ int y5_launch_maxpool_cascade(const void* x, int x_ld, void* y, int y_ld, int y_
     Y5_REQUIRE((long long)(levels - 1) * y_step + c <= y_ld, "maxpool_cascade: levels do not fit the output pitch");
     Y5_REQUIRE(batch > 0 && h > 0 && w > 0, "maxpool_cascade: empty tensor");
     Y5_REQUIRE(y5_aligned16(x) && y5_aligned16(y), "maxpool_cascade: pointers must be 16-byte aligned");
+    const f16* xp = static_cast<const f16*>(x);
+    f16* yp = static_cast<f16*>(y);
+    const size_t sep = (size_t)3 * h * w * 16;  // separable kernel: three planes per vector
+    if (c % 16 == 0 && 2 * sep <= 64 * 1024) {
+        hipLaunchKernelGGL((maxpool_cascade_sep_kernel<2>), dim3((unsigned)(batch * (c / 16))), dim3(kThreads), 2 * sep, s, xp, x_ld, yp,
+                           y_ld, y_step, levels, h, w, c / 16, k);
+        Y5_LAUNCH_CHECK("maxpool_cascade_sep_kernel");
+        return Y5_OK;
+    }
+    if (sep <= 64 * 1024) {
+        hipLaunchKernelGGL((maxpool_cascade_sep_kernel<1>), dim3((unsigned)(batch * (c / 8))), dim3(kThreads), sep, s, xp, x_ld, yp, y_ld,
+                           y_step, levels, h, w, c / 8, k);
+        Y5_LAUNCH_CHECK("maxpool_cascade_sep_kernel");
+        return Y5_OK;
+    }
     const size_t lds = (size_t)2 * h * w * 16;
     Y5_REQUIRE(lds <= 64 * 1024, "maxpool_cascade: %dx%d plane does not fit in LDS", h, w);
     hipLaunchKernelGGL(maxpool_cascade_kernel, dim3((unsigned)(batch * (c / 8))), dim3(kThreads), lds, s, static_cast<const f16*>(x),
