@@ -100,6 +100,18 @@ int y5_conv_num_variants(void);
 int y5_conv_chain_f16(const y5_conv_desc* first, const y5_conv_desc* second, int keep_first, int variant, y5_stream_t stream);
 int y5_conv_chain_num_variants(void);
 
+/* A 1x1 stride-1 convolution whose input is the channel concatenation [nearest-2x-upsampled x | x2], without building
+ * the upsampled tensor or the concatenation.
+ * Replaces: nn.Upsample(None, 2, 'nearest') -> Concat -> the 1x1 convolutions that read it (models/yolov5s.yaml:30-32 and
+ * :34-36: layers 11-13 and 15-17; BottleneckCSP.cv1 / cv2, models/common.py:59-61).
+ * Descriptor as for y5_conv_f16 with ksize = 1, stride = 1, pad = 0 and these meanings: h = ho, w_in = wo = the OUTPUT
+ * size (even); x = the half-resolution tensor (batch, ho/2, wo/2, cin) with pitch x_ld, cin a multiple of 64; x2 =
+ * (batch, ho, wo, cin2) with pitch x2_ld.  A weight row holds cin + cin2 values, x's channels first (kpad >= cin + cin2).
+ * Output pixel (oy, ox) reads x at (oy/2, ox/2) and x2 at (oy, ox).  variant: 0 or 1..y5_conv_cat2_num_variants().
+ * Same values as upsampling, concatenating and calling y5_conv_f16. */
+int y5_conv_cat2_f16(const y5_conv_desc* d, const void* x2, int x2_ld, int cin2, y5_stream_t stream);
+int y5_conv_cat2_num_variants(void);
+
 /* Focus followed by its 3x3 stride-1 pad-1 convolution, straight from the NCHW image, without materialising the
  * space-to-depth tensor.  Replaces: Focus.forward  models/common.py:85-86 (four strided slices + cat + self.conv).
  * Same descriptor and post-ops as y5_conv_f16 with these meanings: x = image (batch, cin = 3, h, w_in) fp16 NCHW
@@ -326,6 +338,7 @@ int y5_plan_add_decode(y5_plan* p, const y5_decode_desc* d);
 int y5_plan_add_decode_multi(y5_plan* p, const y5_decode_desc* levels, int n_levels);
 int y5_plan_add_detect(y5_plan* p, const y5_conv_desc* conv, const y5_decode_desc* d, int variant);
 int y5_plan_add_conv_chain(y5_plan* p, const y5_conv_desc* first, const y5_conv_desc* second, int keep_first, int variant);
+int y5_plan_add_conv_cat2(y5_plan* p, const y5_conv_desc* d, const void* x2, int x2_ld, int cin2);
 /* Mark the op recorded last.  Y5_PLAN_SIDE: y5_plan_run launches it on a second stream owned by the plan, ordered
  * after everything issued before it on the caller's stream -- for an op whose result is needed only much later (the
  * Detect convs of the finer pyramid levels, which can run beside the rest of the head).  Y5_PLAN_JOIN: the caller's
@@ -356,6 +369,7 @@ int y5_plan_profile(y5_plan* p, void* const* ext, int n_ext, y5_stream_t stream,
 #define Y5_OP_CONV_CHAIN 13
 #define Y5_OP_STEM_CONV 14
 #define Y5_OP_STEM_CONV_U8 15
+#define Y5_OP_CONV_CAT2 16
 int y5_plan_op_info(const y5_plan* p, int i, int* kind, double* flops, double* bytes);
 
 #ifdef __cplusplus

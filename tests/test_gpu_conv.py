@@ -429,3 +429,53 @@ def test_stem_conv_from_the_nchw_image(dev, shape):
         assert not bool(torch.isnan(y).any()), 'stem conv left output elements unwritten'
         assert bool((y[..., Co:] == 0).all()), 'padding channels must be zero'
         close(y[..., :Co].permute(0, 3, 1, 2), ref)
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 64, 40, 24, 16), (1, 128, 72, 255, 40, 40), (3, 256, 256, 256, 8, 12), (2, 64, 8, 16, 6, 10),
+                                   (1, 192, 104, 136, 20, 18)], ids=lambda s: 'x'.join(map(str, s)))
+def test_conv_cat2_equals_upsample_concat_conv(dev, shape):
+    """y5_conv_cat2_f16 (1x1 conv of [nearest-2x-upsampled a | b], neither tensor built) against upsampling, concatenating
+    and y5_conv_f16, for every compiled tile shape; with residual, bias, folded BatchNorm and LeakyReLU."""
+    lib = _lib.lib()
+    B, Ca, Cb, Co, H, W = shape  # H, W: the output (= b's) size
+    g = torch.Generator().manual_seed(sum(shape))
+    st = _lib.current_stream()
+    cbp, cop = (Cb + 7) // 8 * 8, (Co + 7) // 8 * 8
+    a_ld = Ca + 16   # pitched sources
+    a = torch.zeros(B, H // 2, W // 2, a_ld, dtype=torch.float16, device=dev)
+    a[..., :Ca] = torch.randn(B, H // 2, W // 2, Ca, generator=g).half().to(dev)
+    b = torch.zeros(B, H, W, cbp, dtype=torch.float16, device=dev)
+    b[..., :Cb] = torch.randn(B, H, W, Cb, generator=g).half().to(dev)
+    cat = torch.cat((a[..., :Ca].repeat_interleave(2, 1).repeat_interleave(2, 2), b), 3).contiguous()
+    w = torch.zeros(Co, Ca + cbp, 1, 1)
+    w[:, :Ca + Cb] = torch.randn(Co, Ca + Cb, 1, 1, generator=g) / (Ca + Cb) ** 0.5
+    w = w.half().to(dev)
+    sc, sh = (torch.rand(Co, generator=g) + 0.5).to(dev), torch.randn(Co, generator=g).to(dev)
+    res = torch.zeros(B, H, W, cop, dtype=torch.float16, device=dev)
+    res[..., :Co] = torch.randn(B, H, W, Co, generator=g).half().to(dev)
+    for use_res in (False, True):
+        d, y, keep = _desc(dev, cat, w, scale=sc, shift=sh, slope=0.1, res=res if use_res else None)
+        _lib.check(lib.y5_conv_f16(C.byref(d), st))
+        torch.cuda.synchronize()
+        ref = y.clone()
+        d.x, d.cin, d.x_ld = a.data_ptr(), Ca, a_ld
+        taken = 0
+        for v in range(lib.y5_conv_cat2_num_variants() + 1):
+            y.fill_(float('nan'))
+            d.variant = v
+            rc = lib.y5_conv_cat2_f16(C.byref(d), b.data_ptr(), cbp, cbp, st)
+            if v and rc == _lib.EINVAL:
+                continue
+            _lib.check(rc)
+            torch.cuda.synchronize()
+            taken += 1
+            close(y.permute(0, 3, 1, 2), ref.permute(0, 3, 1, 2))
+        assert taken >= 5
+    # rejected: odd output size, a first source that is not a multiple of 64 channels wide, a 3x3 kernel
+    d.variant = 0
+    d.cin = 56
+    assert lib.y5_conv_cat2_f16(C.byref(d), b.data_ptr(), cbp, cbp, st) == _lib.EINVAL
+    d.cin, d.ksize, d.pad = Ca, 3, 1
+    assert lib.y5_conv_cat2_f16(C.byref(d), b.data_ptr(), cbp, cbp, st) == _lib.EINVAL
+    d.ksize, d.pad, d.ho, d.h = 1, 0, H + 1, H + 1
+    assert lib.y5_conv_cat2_f16(C.byref(d), b.data_ptr(), cbp, cbp, st) == _lib.EINVAL

@@ -14,7 +14,7 @@ Y5_MAX_LEVELS = 4
 PLAN_SIDE, PLAN_JOIN = 1, 2
 ACT_NONE, ACT_LEAKY = 0, 1
 OK, EINVAL, EHIP, ENOMEM, EWORKSPACE = 0, -1, -2, -3, -4  # y5_status in include/y5hip.h
-OP_NAMES = {14: 'focus_conv', 15: 'focus_conv', 13: 'conv', 12: 'detect', 8: 'focus_conv', 9: 'decode', 10: 'focus_conv', 11: 'normalize', 1: 'conv', 2: 'pack', 3: 'maxpool', 4: 'upsample', 5: 'copy', 6: 'decode', 7: 'maxpool'}
+OP_NAMES = {16: 'conv', 14: 'focus_conv', 15: 'focus_conv', 13: 'conv', 12: 'detect', 8: 'focus_conv', 9: 'decode', 10: 'focus_conv', 11: 'normalize', 1: 'conv', 2: 'pack', 3: 'maxpool', 4: 'upsample', 5: 'copy', 6: 'decode', 7: 'maxpool'}
 
 
 class ConvDesc(C.Structure):
@@ -71,6 +71,8 @@ SIGNATURES = {
     'y5_detect_num_variants': (_i, []),
     'y5_conv_chain_f16': (_i, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), C.c_int, C.c_int, _s]),
     'y5_conv_chain_num_variants': (_i, []),
+    'y5_conv_cat2_f16': (_i, [C.POINTER(ConvDesc), _p, _i, _i, _s]),
+    'y5_conv_cat2_num_variants': (_i, []),
     'y5_sigmoid_f16': (_i, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, _s]),
     'y5_nms_workspace_bytes': (C.c_size_t, [_i, _i]),
     'y5_nms_batched': (_i, [C.POINTER(NmsDesc), _s]),
@@ -96,6 +98,7 @@ SIGNATURES = {
     'y5_plan_add_decode_multi': (_i, [_p, C.POINTER(DecodeDesc), C.c_int]),
     'y5_plan_add_detect': (_i, [_p, C.POINTER(ConvDesc), C.POINTER(DecodeDesc), C.c_int]),
     'y5_plan_add_conv_chain': (_i, [_p, C.POINTER(ConvDesc), C.POINTER(ConvDesc), C.c_int, C.c_int]),
+    'y5_plan_add_conv_cat2': (_i, [_p, C.POINTER(ConvDesc), _p, _i, _i]),
     'y5_plan_mark_last': (_i, [_p, C.c_int]),
     'y5_plan_num_ops': (_i, [_p]),
     'y5_plan_run': (_i, [_p, C.POINTER(_p), _i, _s]),

@@ -127,6 +127,13 @@ extern "C" int y5_conv_chain_f16(const y5_conv_desc* first, const y5_conv_desc* 
 
 extern "C" int y5_conv_chain_num_variants(void) { return y5_conv_lw_count(); }
 
+extern "C" int y5_conv_cat2_f16(const y5_conv_desc* d, const void* x2, int x2_ld, int cin2, y5_stream_t stream) {
+    Y5_REQUIRE(d, "conv_cat2: null descriptor");
+    return y5_launch_conv_cat2(*d, x2, x2_ld, cin2, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int y5_conv_cat2_num_variants(void) { return y5_conv_cat2_variant_count(); }
+
 // ------------------------------------------------------------------------------------------
 // launch plan
 // ------------------------------------------------------------------------------------------
@@ -147,6 +154,7 @@ struct Op {
     int kind = 0;
     y5_conv_desc conv{};
     y5_conv_desc conv2{};  // Y5_OP_CONV_CHAIN: the second convolution; i[0] variant, i[1] keep_first
+                           // Y5_OP_CONV_CAT2: x = the second source, x_ld its pitch, cin its channels
     y5_decode_desc dec{};
     y5_decode_desc decm[Y5_MAX_LEVELS] = {};  // Y5_OP_DECODE_MULTI: i[0] levels
     // generic pointwise arguments
@@ -218,6 +226,13 @@ bool set_ptr(Op& op, int field, const void* v) {
             else if (field == 3) op.conv2.y = nv;
             else return false;
             return true;
+        case Y5_OP_CONV_CAT2:
+            if (field == 0) op.conv.x = v;
+            else if (field == 1) op.conv.y = nv;
+            else if (field == 2) op.conv.res = v;
+            else if (field == 3) op.conv2.x = v;
+            else return false;
+            return true;
         case Y5_OP_DETECT:
             if (field == 0) op.conv.x = v;
             else if (field == 1) op.dec.x_out = nv;
@@ -256,6 +271,7 @@ int run_op(const Op& op, hipStream_t s) {
         case Y5_OP_DECODE_MULTI: return y5_launch_decode_multi(op.decm, op.i[0], s);
         case Y5_OP_DETECT: return y5_launch_detect(op.conv, op.dec, op.i[0], s);
         case Y5_OP_CONV_CHAIN: return y5_launch_conv_chain(op.conv, op.conv2, op.i[1], op.i[0], s);
+        case Y5_OP_CONV_CAT2: return y5_launch_conv_cat2(op.conv, op.conv2.x, op.conv2.x_ld, op.conv2.cin, s);
     }
     return y5_fail(Y5_EINVAL, "plan: unknown op kind %d", op.kind);
 }
@@ -451,6 +467,27 @@ extern "C" int y5_plan_add_detect(y5_plan* p, const y5_conv_desc* conv, const y5
         op.flops = 2.0 * m * conv->cout * conv->cin;
         // read the feature map and the weights once, write z (and the permuted raw copy, when asked for) once, fp16
         op.bytes = 2.0 * (m * conv->cin + (double)conv->cout * conv->cin + (d->x_out ? 2.0 : 1.0) * m * outs);
+        p->ops.push_back(op);
+        return Y5_OK;
+    });
+}
+
+extern "C" int y5_plan_add_conv_cat2(y5_plan* p, const y5_conv_desc* d, const void* x2, int x2_ld, int cin2) {
+    Y5_REQUIRE(p && d && x2, "plan_add_conv_cat2: null argument");
+    return guarded([&]() {
+        Op op;
+        op.kind = Y5_OP_CONV_CAT2;
+        op.conv = *d;
+        op.conv2.x = x2;
+        op.conv2.x_ld = x2_ld;
+        op.conv2.cin = cin2;
+        note_ptr(p, op, 0, d->x);
+        note_ptr(p, op, 1, d->y);
+        note_ptr(p, op, 2, d->res);
+        note_ptr(p, op, 3, x2);
+        const double m = (double)d->batch * d->ho * d->wo;
+        op.flops = 2.0 * m * d->cout * (d->cin + cin2);
+        op.bytes = 2.0 * (m / 4 * d->cin + m * cin2 + m * d->cout * (d->res ? 2 : 1) + (double)d->cout * (d->cin + cin2));
         p->ops.push_back(op);
         return Y5_OK;
     });

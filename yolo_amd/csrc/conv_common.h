@@ -47,6 +47,10 @@ struct ConvArgs {
     f16* y2;
     int w2_ld, y2_ld, Cout2, keep_first;
     float slope2;
+    // 1x1 convolution of a concatenation (conv_igemm.hip, CAT2): input channels [0, Cin) are x, a tensor of half the
+    // output's height and width read at (oy/2, ox/2) (nearest 2x upsampling); channels [Cin, K) are x2 at (oy, ox)
+    const f16* x2;
+    int x2_ld, x2_bytes;
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -45,9 +45,12 @@ struct IgemmCfg {
 // (0, 0) and nine validity bits -- a DMA instruction then costs ~8 instructions of address work instead of ~20.  Where
 // Cin is not a multiple of BK the tap's last step stages zeros for the missing channels (and whatever weights follow in
 // the row: their products vanish).
-template <int BM, int BN, int WM, int WN, int KS, int S, int BK, bool DIRECT, bool UT = false>
+// CAT2 (1x1, DIRECT): the input is the channel concatenation [nearest-2x-upsampled x | x2] that is never built: K-steps
+// below Cin (a multiple of BK) fetch pixel (oy/2, ox/2) of the half-resolution x, the rest pixel (oy, ox) of x2.
+template <int BM, int BN, int WM, int WN, int KS, int S, int BK, bool DIRECT, bool UT = false, bool CAT2 = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs a) {
     static_assert(!UT || (KS == 3 && !DIRECT), "uniform-tap addressing is for 3x3 convolutions");
+    static_assert(!CAT2 || DIRECT, "the two-source input is for 1x1 convolutions");
     constexpr int NW = WM * WN, NT = 64 * NW;
     static_assert(NW == 4 || NW == 8, "four or eight waves per workgroup");
     static_assert(BK == 32 || BK == 64, "K-step is 32 or 64");
@@ -86,15 +89,24 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
     const int kc = (BK == 64) ? ((t & 7) ^ ((row0 >> 1) & 7)) : ((t & 3) ^ ((row0 >> 2) & 3));
     // Sources are byte offsets from a.x / a.w, fetched through buffer descriptors (conv_common.h: dma16_buf).
     const i32x4 xr = make_buf(a.x, a.x_bytes), wr = make_buf(a.w, a.w_bytes);
+    const i32x4 xr2 = CAT2 ? make_buf(a.x2, a.x2_bytes) : xr;
     int hi0[A_CH], wi0[A_CH];
     int xrow[A_CH];  // DIRECT: offset of the pixel; otherwise of pixel (b, 0, 0)
+    int acur2[CAT2 ? A_CH : 1];  // CAT2: running offset of the pixel in x2
     bool mvalid[A_CH];
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
         const int m = m0 + row0 + RPI * i;
         mvalid[i] = m < a.M;
         const unsigned mm = mvalid[i] ? (unsigned)m : 0u;
-        if (DIRECT) {
+        if (CAT2) {
+            const unsigned b = fdiv(mm, a.div_hw);
+            const unsigned rem = mm - b * (unsigned)(a.Ho * a.Wo);
+            const unsigned oy = fdiv(rem, a.div_wo), ox = rem - oy * (unsigned)a.Wo;
+            hi0[i] = wi0[i] = 0;
+            xrow[i] = (int)(((b * (unsigned)(a.Ho >> 1) + (oy >> 1)) * (unsigned)(a.Wo >> 1) + (ox >> 1)) * (unsigned)a.x_ld * 2u);
+            acur2[i] = (int)(mm * (unsigned)a.x2_ld * 2u) + kc * 16;
+        } else if (DIRECT) {
             hi0[i] = wi0[i] = 0;
             xrow[i] = (int)(mm * (unsigned)a.x_ld * 2u);
         } else {
@@ -148,6 +160,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
     // MFMA groups of the step being multiplied was measured and gains nothing: the time goes into the DMA issue itself.)
     int st_r = 0, st_q = 0;
     bool st_kvalid = false;
+    int k0u = 0;  // CAT2: first channel of the K-step being fetched (wave-uniform)
     auto step_begin = [&]() {
         if (UT) {
             const int r = (ut_tap * 11) >> 5, q = ut_tap - 3 * r;
@@ -168,6 +181,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
             unsigned vo;
             if (UT) {
                 vo = ((vmask[i] & ut_bit) && ut_c0 + kc * 8 < a.Cin) ? (unsigned)(acur[i] + ut_off) : Y5_BUF_OOB;
+            } else if (CAT2) {
+                if (k0u < a.Cin) {
+                    vo = mvalid[i] ? (unsigned)acur[i] : Y5_BUF_OOB;
+                    acur[i] += BK * 2;
+                } else {
+                    vo = (st_kvalid && mvalid[i]) ? (unsigned)acur2[i] : Y5_BUF_OOB;
+                    acur2[i] += BK * 2;
+                    dma16_buf(xr2, vo, lds0 + stage * STAGE_BYTES + wave * 1024 + i * PIECE);
+                    return;
+                }
             } else if (DIRECT) {
                 vo = (st_kvalid && mvalid[i]) ? (unsigned)acur[i] : Y5_BUF_OOB;
                 acur[i] += BK * 2;
@@ -193,6 +216,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
             return;
         }
         kpos += BK;
+        if (CAT2) k0u += BK;
         if (KS > 1) {
             cch += BK;
             while (cch >= a.Cin) {
@@ -365,6 +389,40 @@ int launch_tile(const ConvArgs& a0, int ksize, bool direct, hipStream_t s) {
     return Y5_OK;
 }
 
+template <int BM, int BN, int WM, int WN, int S, int BK>
+int launch_cat2(const ConvArgs& a0, hipStream_t s) {
+    ConvArgs a = a0;
+    const long long tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = (a.Cout + BN - 1) / BN;
+    a.nk = (a.K + BK - 1) / BK;
+    const long long total = tiles_m * a.tiles_n;
+    if (total <= 0 || total > 0x7fffffffLL) return y5_fail(Y5_EINVAL, "conv_cat2: tile count %lld out of range", total);
+    a.tiles_total = (int)total;
+    typedef IgemmCfg<BM, BN, WM, WN, S, BK> Cfg;
+    static std::atomic<unsigned long long> attr_set{0};
+    const unsigned long long attr_set_bit = 1ull << y5_current_device();
+    if (!(attr_set.load() & attr_set_bit)) {
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, 1, S, BK, true, false, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+        attr_set.fetch_or(attr_set_bit);
+    }
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1, S, BK, true, false, true>), dim3((unsigned)total), dim3(Cfg::NT), Cfg::SMEM, s, a);
+    Y5_LAUNCH_CHECK("conv_igemm_kernel<cat2>");
+    return Y5_OK;
+}
+
+struct Cat2Variant {
+    int bn;
+    int (*launch)(const ConvArgs&, hipStream_t);
+};
+#define Y5_C2(BM, BN, WM, WN, S) {BN, &launch_cat2<BM, BN, WM, WN, S, 64>}
+const Cat2Variant kCat2[] = {
+    Y5_C2(128, 128, 2, 2, 2), Y5_C2(128, 128, 2, 4, 3), Y5_C2(256, 128, 4, 2, 2), Y5_C2(256, 128, 4, 2, 3),
+    Y5_C2(128, 64, 2, 2, 3),  Y5_C2(64, 128, 2, 2, 3),  Y5_C2(256, 256, 2, 4, 2), Y5_C2(256, 64, 4, 2, 3),
+};
+#undef Y5_C2
+constexpr int kNumCat2 = (int)(sizeof(kCat2) / sizeof(kCat2[0]));
+
 // Every compiled tile configuration. Index + 1 is the public variant id (0 = choose by rule); ids past the end
 // of this table select the other kernel families in turn (conv_halo.hip, conv_ws1x1.hip, conv3x3_ws.hip, conv_lw.hip).
 struct Variant {
@@ -516,3 +574,52 @@ int y5_launch_conv(const y5_conv_desc& d, hipStream_t s) {
 }
 
 int y5_conv_variant_count() { return kNumIgemm + kNumHalo + kNumWs + kNumWs3 + y5_conv_lw_count(); }
+
+int y5_conv_cat2_variant_count() { return kNumCat2; }
+
+// d: the convolution with x = the half-resolution tensor (batch, ho/2, wo/2, cin), h = ho, w_in = wo the OUTPUT
+// resolution; x2 (batch, ho, wo, cin2).  Weight rows hold K = cin + cin2 values, x's channels first.
+int y5_launch_conv_cat2(const y5_conv_desc& d, const void* x2, int x2_ld, int cin2, hipStream_t s) {
+    Y5_REQUIRE(d.x && x2 && d.w && d.y, "conv_cat2: null tensor pointer");
+    Y5_REQUIRE(d.ksize == 1 && d.stride == 1 && d.pad == 0, "conv_cat2: only 1x1 stride-1 convolutions");
+    Y5_REQUIRE(d.batch > 0 && d.ho > 0 && d.wo > 0 && d.h == d.ho && d.w_in == d.wo, "conv_cat2: h, w_in must equal the output size %dx%d", d.ho, d.wo);
+    Y5_REQUIRE(d.ho % 2 == 0 && d.wo % 2 == 0, "conv_cat2: output %dx%d must be even (2x upsampled source)", d.ho, d.wo);
+    Y5_REQUIRE((long long)d.batch * d.ho * d.wo < 0x7fffffffLL, "conv_cat2: more than 2^31 pixels");
+    Y5_REQUIRE(d.cin > 0 && d.cin % 64 == 0 && d.x_ld % 8 == 0 && d.x_ld >= d.cin, "conv_cat2: cin %d must be a multiple of 64, x_ld %d of 8", d.cin, d.x_ld);
+    Y5_REQUIRE(cin2 > 0 && cin2 % 8 == 0 && x2_ld % 8 == 0 && x2_ld >= cin2, "conv_cat2: cin2 %d / x2_ld %d must be multiples of 8", cin2, x2_ld);
+    Y5_REQUIRE(d.cout > 0 && d.cout % 8 == 0 && d.y_ld % 8 == 0 && d.y_ld >= d.cout, "conv_cat2: cout %d / y_ld %d must be multiples of 8", d.cout, d.y_ld);
+    Y5_REQUIRE(d.kpad % 64 == 0 && d.kpad >= d.cin + cin2, "conv_cat2: kpad %d too small or not a multiple of 64", d.kpad);
+    Y5_REQUIRE(d.w_rows % 128 == 0 && d.w_rows >= d.cout, "conv_cat2: w_rows %d must be a multiple of 128 >= cout", d.w_rows);
+    Y5_REQUIRE(!d.scale || d.shift, "conv_cat2: scale without shift");
+    Y5_REQUIRE(!d.res || (d.res_ld % 8 == 0 && d.res_ld >= d.cout), "conv_cat2: bad residual pitch %d", d.res_ld);
+    Y5_REQUIRE(y5_aligned16(d.x) && y5_aligned16(x2) && y5_aligned16(d.w) && y5_aligned16(d.y) && y5_aligned16(d.res), "conv_cat2: pointers must be 16-byte aligned");
+    Y5_REQUIRE(y5_aligned16(d.bias) && y5_aligned16(d.scale) && y5_aligned16(d.shift), "conv_cat2: per-channel vectors must be 16-byte aligned");
+    Y5_REQUIRE(d.act == Y5_ACT_NONE || d.act == Y5_ACT_LEAKY, "conv_cat2: unknown activation %d", d.act);
+    Y5_REQUIRE(d.act == Y5_ACT_NONE || (d.slope > 0.f && d.slope <= 1.f), "conv_cat2: LeakyReLU slope %g outside (0, 1]", (double)d.slope);
+    Y5_REQUIRE(d.variant >= 0 && d.variant <= kNumCat2, "conv_cat2: variant %d out of range 0..%d", d.variant, kNumCat2);
+    const long long x_span = (((long long)d.batch * (d.ho / 2) * (d.wo / 2) - 1) * d.x_ld + d.cin) * 2;
+    const long long x2_span = (((long long)d.batch * d.ho * d.wo - 1) * x2_ld + cin2) * 2;
+    Y5_REQUIRE(x_span < 0x7fffffffLL && x2_span < 0x7fffffffLL && (long long)d.w_rows * d.kpad * 2 < 0x7fffffffLL, "conv_cat2: a tensor of 2 GiB or more");
+    ConvArgs a{};
+    a.x = static_cast<const f16*>(d.x);
+    a.x2 = static_cast<const f16*>(x2);
+    a.w = static_cast<const f16*>(d.w);
+    a.bias = d.bias; a.scale = d.scale; a.shift = d.shift;
+    a.res = static_cast<const f16*>(d.res);
+    a.y = static_cast<f16*>(d.y);
+    a.M = (long long)d.batch * d.ho * d.wo;
+    a.H = d.ho; a.W = d.wo; a.Cin = d.cin; a.x_ld = d.x_ld; a.x2_ld = x2_ld;
+    a.Ho = d.ho; a.Wo = d.wo; a.Cout = d.cout; a.y_ld = d.y_ld; a.res_ld = d.res_ld;
+    a.stride = 1; a.pad = 0; a.K = d.cin + cin2;
+    a.w_ld = d.kpad;
+    a.slope = d.act == Y5_ACT_LEAKY ? d.slope : 1.f;
+    a.div_hw = make_fastdiv((unsigned)(d.ho * d.wo));
+    a.div_wo = make_fastdiv((unsigned)d.wo);
+    a.div_cin = make_fastdiv((unsigned)d.cin);
+    a.x_bytes = (int)x_span; a.x2_bytes = (int)x2_span;
+    a.w_bytes = (int)((long long)d.w_rows * d.kpad * 2);
+    const Cat2Variant& v = kCat2[d.variant > 0 ? d.variant - 1 : 0];
+    if ((long long)((d.cout + v.bn - 1) / v.bn) * v.bn > d.w_rows)
+        return y5_fail(Y5_EINVAL, "conv_cat2: variant %d reads %d-row weight tiles, w_rows %d is too small for cout %d", d.variant, v.bn, d.w_rows, d.cout);
+    return v.launch(a, s);
+}

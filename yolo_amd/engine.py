@@ -123,6 +123,16 @@ class Act:
         return Act(self.buf, self.off + off, self.ld, self.batch, self.h, self.w, segs)
 
 
+class Cat2(Act):
+    """The channel concatenation [nearest-2x-upsampled a | b] as a tensor that is never built: the 1x1 convolutions that
+    read it fetch a at half resolution and b directly (y5_conv_cat2_f16)."""
+
+    def __init__(self, a, b):
+        super().__init__(None, 0, 0, b.batch, b.h, b.w, list(a.segs) + list(b.segs))
+        self.a, self.b = a, b
+        self.real = None  # the materialised tensor, if some consumer needed one
+
+
 class Unsupported(Exception):
     pass
 
@@ -230,6 +240,12 @@ class Plan:
                 raise Unsupported('conv weights must be fp16 on the input device')
         if [p for _, p in weights] != [p for _, p in out.segs] or [w.shape[0] for w, _ in weights] != [c for c, _ in out.segs]:
             raise Unsupported('conv output slice mismatch')
+        cat2 = None
+        if isinstance(x, Cat2):
+            if k == 1 and s == 1 and image is None and self._defer is None and x.real is None:
+                cat2 = x
+            else:
+                x = self._materialise(x)
         ho = (x.h + 2 * (k // 2) - k) // s + 1
         wo = (x.w + 2 * (k // 2) - k) // s + 1
         if (ho, wo) != (out.h, out.w):
@@ -268,6 +284,13 @@ class Plan:
             self.labels.append('%s %s%sconv3x3 %d->%d @%dx%d' % (label, 'u8/255+' if u8 else '', 'image ' if stem else 'focus+',
                                                                    x.c_log, out.c_log, ho, wo))
             return
+        if cat2 is not None:
+            a, b = cat2.a, cat2.b
+            d.x, d.cin, d.x_ld = a.ptr, a.c_pad, a.ld
+            d.variant = self._tune_cat2(d, cat2)
+            _lib.check(self.lib.y5_plan_add_conv_cat2(self.handle, C.byref(d), b.ptr, b.ld, b.c_pad))
+            self.labels.append('%s conv1x1 s1 [up2x %d | %d]->%d @%dx%d c%d' % (label, a.c_log, b.c_log, out.c_log, ho, wo, d.variant))
+            return
         text = '%s conv%dx%d s%d %d->%d @%dx%d' % (label, k, k, s, x.c_log, out.c_log, ho, wo)
         if self._defer is not None:  # the caller combines the descriptors itself (_csp: chained convolutions)
             self._defer.append((text, d, x))
@@ -275,6 +298,45 @@ class Plan:
         d.variant = self._tune(d, x)
         _lib.check(self.lib.y5_plan_add_conv(self.handle, C.byref(d)))
         self.labels.append('%s v%d' % (text, d.variant))
+
+    def _materialise(self, cat):
+        """The real tensor behind a Cat2, built (once) for a consumer that cannot read the two sources itself."""
+        if cat.real is None:
+            a, b = cat.a, cat.b
+            real = self._new_act(b.batch, b.h, b.w, cat.segs)
+            _lib.check(self.lib.y5_plan_add_upsample2x(self.handle, a.ptr, a.ld, real.ptr, real.ld, a.batch, a.h, a.w, a.c_pad, 0))
+            self.labels.append('upsample2x nearest (concat materialised)')
+            _lib.check(self.lib.y5_plan_add_copy_channels(self.handle, b.ptr, b.ld, real.ptr + 2 * a.c_pad, real.ld,
+                                                           b.batch * b.h * b.w, b.c_pad))
+            self.labels.append('copy part (concat materialised)')
+            cat.real = real
+        return cat.real
+
+    def _tune_cat2(self, d, cat):
+        """Fastest tile configuration of the two-source 1x1 convolution for this shape (timed, cached per process)."""
+        if os.environ.get('Y5_AUTOTUNE', '1') == '0':
+            return 0
+        a, b = cat.a, cat.b
+        key = ('cat2', d.batch, d.ho, d.wo, a.c_pad, a.ld, b.c_pad, b.ld, d.cout, d.y_ld, bool(d.res), bool(d.bias), bool(d.scale))
+        if key not in _TUNED:
+            a.buf.uniform_(-1.0, 1.0)
+            b.buf.uniform_(-1.0, 1.0)
+            stream = _lib.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            best, best_t = 0, float('inf')
+            for v in range(1, self.lib.y5_conv_cat2_num_variants() + 1):
+                d.variant = v
+                if self.lib.y5_conv_cat2_f16(C.byref(d), b.ptr, b.ld, b.c_pad, stream) != 0:
+                    continue
+                e0.record()
+                for _ in range(4):
+                    self.lib.y5_conv_cat2_f16(C.byref(d), b.ptr, b.ld, b.c_pad, stream)
+                e1.record()
+                e1.synchronize()
+                if e0.elapsed_time(e1) < best_t:
+                    best, best_t = v, e0.elapsed_time(e1)
+            _TUNED[key], _TUNED_MS[key] = best, best_t / 4
+        return _TUNED[key]
 
     def _emit_chain(self, defs, keep_first=0):
         """Record two deferred convolutions, the second a 1x1 of the first one's output, either as ONE kernel
@@ -464,8 +526,39 @@ class Plan:
         self.homes = {}          # producer layer index -> (concat Act, channel offset)
         self.concat_acts = {}    # concat layer index -> Act
         producer_types = (common.Conv, common.Focus, common.BottleneckCSP, common.SPP, common.Bottleneck, nn.Upsample)
+        # nn.Upsample(nearest, 2) -> Concat([up, skip]) read only by 1x1 convolutions: neither tensor is built, the
+        # convolutions read the low-resolution tensor and the skip tensor themselves (Cat2)
+        consumers = {j: [] for j in range(len(layers))}
         for i, m in enumerate(layers):
-            if not isinstance(m, common.Concat):
+            for j in (m.f if isinstance(m.f, (list, tuple)) else [m.f]):
+                src_idx = i + j if j < 0 else j
+                if src_idx >= 0:
+                    consumers[src_idx].append(i)
+        self.lazy_cat = {}   # concat layer index -> (upsample layer index, skip layer index)
+        self.lazy_up = {}    # upsample layer index -> its source layer index
+        if os.environ.get('Y5_CAT2_FUSE', '1') != '0':
+            for i, m in enumerate(layers):
+                if not isinstance(m, common.Concat) or not isinstance(m.f, (list, tuple)) or len(m.f) != 2:
+                    continue
+                ju, jb = [i + j if j < 0 else j for j in m.f]
+                up = layers[ju] if ju >= 0 else None
+                if not (isinstance(up, nn.Upsample) and up.mode == 'nearest' and consumers[ju] == [i] and isinstance(up.f, int)):
+                    continue
+                js = ju + up.f if up.f < 0 else up.f
+                if js < 0 or isinstance(layers[js], common.Concat) or isinstance(layers[jb], (common.Concat, nn.Upsample)) or jb == ju:
+                    continue
+                if shapes[js][0] % 64 != 0 or len(consumers[i]) != 1:
+                    continue
+                cons = layers[consumers[i][0]]
+                if isinstance(cons, common.BottleneckCSP):
+                    ok = _conv_geometry(cons.cv1.conv) == (1, 1) and _conv_geometry(cons.cv2) == (1, 1)
+                else:
+                    ok = isinstance(cons, common.Conv) and _conv_geometry(cons.conv) == (1, 1)
+                if ok:
+                    self.lazy_cat[i] = (ju, jb)
+                    self.lazy_up[ju] = js
+        for i, m in enumerate(layers):
+            if not isinstance(m, common.Concat) or i in self.lazy_cat:
                 continue
             srcs = [i + j if j < 0 else j for j in m.f]
             segs = []
@@ -538,6 +631,11 @@ class Plan:
             elif isinstance(m, common.SPP):
                 out = self._out_for(i, B, h, w, c_log)
                 self._spp(name, m, get(f), out)
+            elif isinstance(m, nn.Upsample) and i in self.lazy_up:
+                out = get(f)   # stands for its own 2x upsampling until the Concat below wraps it
+            elif isinstance(m, common.Concat) and i in self.lazy_cat:
+                ju, jb = self.lazy_cat[i]
+                out = Cat2(outs[ju], outs[jb])
             elif isinstance(m, nn.Upsample):
                 xin = get(f)
                 out = self._out_for(i, B, h, w, c_log)
