@@ -419,6 +419,8 @@ struct Cat2Variant {
 const Cat2Variant kCat2[] = {
     Y5_C2(128, 128, 2, 2, 2), Y5_C2(128, 128, 2, 4, 3), Y5_C2(256, 128, 4, 2, 2), Y5_C2(256, 128, 4, 2, 3),
     Y5_C2(128, 64, 2, 2, 3),  Y5_C2(64, 128, 2, 2, 3),  Y5_C2(256, 256, 2, 4, 2), Y5_C2(256, 64, 4, 2, 3),
+    Y5_C2(128, 128, 2, 4, 2), Y5_C2(128, 128, 2, 2, 3), Y5_C2(64, 64, 2, 2, 3),   Y5_C2(128, 64, 4, 2, 3),
+    Y5_C2(64, 128, 2, 4, 3),  Y5_C2(256, 64, 4, 2, 2),
 };
 #undef Y5_C2
 constexpr int kNumCat2 = (int)(sizeof(kCat2) / sizeof(kCat2[0]));
