@@ -189,6 +189,13 @@ int y5_copy_channels_f16(const void* x, int x_ld, void* y, int y_ld, int64_t pix
  *                     Y5_ACT_NONE or Y5_ACT_LEAKY(slope); res may be NULL (Bottleneck's shortcut,
  *                     models/common.py:43).  y may alias x.
  * ---------------------------------------------------------------------------------------------- */
+/* y5_conv_f16 that also ADDS the per-channel sums of the outputs it stores (the fp16 values, after every post-op) into
+ * partials (fp32 [rows][2*stats_c], zeroed by the caller before the first convolution that adds to it): output channel n
+ * goes to columns stats_off + n (sum) and stats_c + stats_off + n (sum of squares) of row (pixel tile index % rows).
+ * y5_bn_finalize_f32(partials, rows, ...) then replaces y5_bn_stats_f16 + its pass over the tensor.  Only variant 0 and the
+ * im2col kernel family (the first variant ids) accumulate; for the other kernel families the call returns Y5_EINVAL.
+ * fp32 atomics: sums can differ in the last bits between runs. */
+int y5_conv_stats_f16(const y5_conv_desc* d, float* partials, int rows, int stats_c, int stats_off, y5_stream_t stream);
 int y5_bn_stats_rows(int64_t pixels, int c);
 int y5_bn_stats_f16(const void* x, int x_ld, int64_t pixels, int c, float* partials, y5_stream_t stream);
 int y5_bn_finalize_f32(const float* partials, int rows, int64_t count, int c, int c_valid, const float* gamma, const float* beta,

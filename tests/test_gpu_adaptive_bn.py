@@ -275,3 +275,46 @@ def test_fused_model_is_refused():
     model = util.quiet(util.build_model('yolov5s').fuse).cuda()
     with pytest.raises(Unsupported):
         Recalibrator(model).step(torch.zeros(1, 3, 64, 64, dtype=torch.uint8, device='cuda'))
+
+
+@pytest.mark.parametrize('shape', [(2, 32, 32, 40, 24, 3, 1), (3, 64, 104, 20, 20, 1, 1), (1, 128, 256, 20, 12, 3, 2), (2, 24, 13, 17, 9, 3, 1)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_conv_epilogue_statistics(shape):
+    """y5_conv_stats_f16: the same output as y5_conv_f16 (bit for bit, same kernel) and, summed over the partial rows,
+    the per-channel sums of that fp16 output - for every tile shape that accumulates, into a column window of a wider
+    statistics buffer that already holds another tensor's sums."""
+    from tests.test_gpu_conv import _desc
+    L, lib = _lib()
+    B, Ci, Co, H, W, k, s = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    st = L.current_stream()
+    cip, cop = (Ci + 7) // 8 * 8, (Co + 7) // 8 * 8
+    x = torch.zeros(B, H, W, cip, dtype=torch.float16, device='cuda')
+    x[..., :Ci] = torch.randn(B, H, W, Ci, generator=g).half().cuda()
+    w = (torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5).half().cuda()
+    rows, off, ctot = 8, 16, cop + 24
+    taken = 0
+    for v in range(lib.y5_conv_num_variants() + 1):
+        d, y, keep = _desc('cuda', x, w, stride=s)
+        d.variant = v
+        if lib.y5_conv_f16(C.byref(d), st) != 0:
+            continue
+        torch.cuda.synchronize()
+        ref = y.clone()
+        y.fill_(float('nan'))
+        part = torch.zeros(rows, 2 * ctot, dtype=torch.float32, device='cuda')
+        part[:, :off] = 5.0   # somebody else's columns
+        rc = lib.y5_conv_stats_f16(C.byref(d), part.data_ptr(), rows, ctot, off, st)
+        if rc == L.EINVAL:
+            continue          # a kernel family that does not accumulate
+        L.check(rc)
+        torch.cuda.synchronize()
+        taken += 1
+        assert torch.equal(y, ref)
+        yd = ref.double().reshape(-1, cop)
+        sums = part.double().sum(0)
+        assert torch.allclose(sums[off:off + cop], yd.sum(0), rtol=1e-5, atol=1e-3 * yd.abs().max().item())
+        assert torch.allclose(sums[ctot + off:ctot + off + cop], (yd * yd).sum(0), rtol=1e-5, atol=1e-3)
+        assert bool((part[:, :off] == 5.0).all()) and bool((part[:, off + cop:ctot] == 0).all())
+        assert bool((part[:, ctot:ctot + off] == 0).all()) and bool((part[:, ctot + off + cop:] == 0).all())
+    assert taken >= 10

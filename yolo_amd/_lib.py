@@ -61,6 +61,7 @@ SIGNATURES = {
     'y5_maxpool_cascade_f16': (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _s]),
     'y5_upsample2x_f16': (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _s]),
     'y5_copy_channels_f16': (_i, [_p, _i, _p, _i, C.c_int64, _i, _s]),
+    'y5_conv_stats_f16': (_i, [C.POINTER(ConvDesc), _p, _i, _i, _i, _s]),
     'y5_bn_stats_rows': (_i, [C.c_int64, _i]),
     'y5_bn_stats_f16': (_i, [_p, _i, C.c_int64, _i, _p, _s]),
     'y5_bn_finalize_f32': (_i, [_p, _i, C.c_int64, _i, _i, _p, _p, C.c_float, C.c_float, _p, _p, _p, _p, _s]),

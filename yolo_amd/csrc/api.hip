@@ -82,6 +82,12 @@ extern "C" int y5_upsample2x_f16(const void* x, int x_ld, void* y, int y_ld, int
                                  y5_stream_t stream) {
     return y5_launch_upsample2x(x, x_ld, y, y_ld, batch, h, w, c, mode, static_cast<hipStream_t>(stream));
 }
+extern "C" int y5_conv_stats_f16(const y5_conv_desc* d, float* partials, int rows, int stats_c, int stats_off, y5_stream_t stream) {
+    Y5_REQUIRE(d, "conv_stats: null descriptor");
+    const Y5ConvStats st{partials, rows, stats_c, stats_off};
+    return y5_launch_conv(*d, static_cast<hipStream_t>(stream), &st);
+}
+
 extern "C" int y5_bn_stats_rows(int64_t pixels, int c) { return y5_bn_stats_row_count(pixels, c); }
 
 extern "C" int y5_bn_stats_f16(const void* x, int x_ld, int64_t pixels, int c, float* partials, y5_stream_t stream) {

@@ -51,6 +51,10 @@ struct ConvArgs {
     // output's height and width read at (oy/2, ox/2) (nearest 2x upsampling); channels [Cin, K) are x2 at (oy, ox)
     const f16* x2;
     int x2_ld, x2_bytes;
+    // per-channel sums of the stored outputs (conv_igemm.hip epilogue): stats[r][0..stats_c) += sum, [stats_c..2 stats_c) +=
+    // sum of squares, r = M-tile index % stats_rows, channel n at column stats_off + n; nullptr = off
+    float* stats;
+    int stats_rows, stats_c, stats_off;
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -319,6 +319,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
     constexpr int RPP = NT / CPR;        // rows per pass
     const int cc = t % CPR, rr = t / CPR;
     const int n = n0 + cc * 8;
+    const bool want_stats = a.stats != nullptr;  // wave-uniform
+    float ssum[8], ssq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ssum[e] = ssq[e] = 0.f;
     if (n < a.Cout) {
 #pragma unroll
         for (int p = 0; p < BM / RPP; ++p) {
@@ -328,6 +332,35 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
                 f16x8 v = *reinterpret_cast<const f16x8*>(smem + row * EP + cc * 16);
                 if (a.res) v += *reinterpret_cast<const f16x8*>(a.res + (size_t)m * a.res_ld + n);
                 *reinterpret_cast<f16x8*>(a.y + (size_t)m * a.y_ld + n) = v;
+                if (want_stats) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float f = (float)v[e];
+                        ssum[e] += f;
+                        ssq[e] = __builtin_fmaf(f, f, ssq[e]);
+                    }
+                }
+            }
+        }
+    }
+    if (want_stats) {
+        // per-channel sums of what was just stored: the RPP threads of a channel chunk meet in LDS (the staged tile is
+        // dead once every thread has read its rows), one atomic per channel and moment leaves the workgroup
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);  // [RPP][CPR][16]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[(rr * CPR + cc) * 16 + e] = ssum[e];
+            red[(rr * CPR + cc) * 16 + 8 + e] = ssq[e];
+        }
+        __syncthreads();
+        float* srow = a.stats + (size_t)(mt % a.stats_rows) * 2 * a.stats_c + a.stats_off;
+        for (int col = t; col < 2 * BN; col += NT) {
+            const int which = col / BN, ch = col - which * BN;
+            if (n0 + ch < a.Cout) {
+                float acc1 = 0.f;
+                for (int r = 0; r < RPP; ++r) acc1 += red[(r * CPR + (ch >> 3)) * 16 + which * 8 + (ch & 7)];
+                unsafeAtomicAdd(srow + which * a.stats_c + n0 + ch, acc1);
             }
         }
     }
@@ -464,7 +497,7 @@ int find_variant(int bm, int bn, int bk, int s) {
 
 }  // namespace
 
-int y5_launch_conv(const y5_conv_desc& d, hipStream_t s) {
+int y5_launch_conv(const y5_conv_desc& d, hipStream_t s, const Y5ConvStats* st) {
     Y5_REQUIRE(d.x && d.w && d.y, "conv: null tensor pointer");
     Y5_REQUIRE(d.ksize == 1 || d.ksize == 3, "conv: ksize %d not in {1,3}", d.ksize);
     Y5_REQUIRE(d.stride == 1 || d.stride == 2, "conv: stride %d not in {1,2}", d.stride);
@@ -486,6 +519,11 @@ int y5_launch_conv(const y5_conv_desc& d, hipStream_t s) {
 
     Y5_REQUIRE(d.variant >= 0 && d.variant <= kNumIgemm + kNumHalo + kNumWs + kNumWs3 + y5_conv_lw_count(), "conv: variant %d out of range 0..%d",
                d.variant, kNumIgemm + kNumHalo + kNumWs + kNumWs3 + y5_conv_lw_count());
+    if (st) {
+        Y5_REQUIRE(st->partials && st->rows > 0 && st->c > 0 && st->off >= 0 && st->off + d.cout <= st->c, "conv: statistics columns %d..+%d outside 0..%d (rows %d)", st->off, d.cout, st->c, st->rows);
+        Y5_REQUIRE((reinterpret_cast<uintptr_t>(st->partials) & 3) == 0, "conv: misaligned statistics pointer");
+        if (d.variant > kNumIgemm) return y5_fail(Y5_EINVAL, "conv: variant %d does not accumulate statistics (variants 1..%d do)", d.variant, kNumIgemm);
+    }
     if (d.variant > kNumIgemm + kNumHalo + kNumWs + kNumWs3) {
         int rc = Y5_OK;
         if (y5_try_conv_lw(d, s, d.variant - kNumIgemm - kNumHalo - kNumWs - kNumWs3, &rc)) return rc;
@@ -501,7 +539,7 @@ int y5_launch_conv(const y5_conv_desc& d, hipStream_t s) {
         if (y5_try_conv_ws1x1(d, s, d.variant - kNumIgemm - kNumHalo, &rc)) return rc;
         return y5_fail(Y5_EINVAL, "conv: the weight-stationary variant %d does not apply to this shape", d.variant);
     }
-    if (d.variant > kNumIgemm || (d.variant == 0 && !getenv("Y5_NO_HALO"))) {
+    if (d.variant > kNumIgemm || (d.variant == 0 && !st && !getenv("Y5_NO_HALO"))) {
         int rc = Y5_OK;
         const int bn = d.variant == 0 ? 0 : (128 >> (d.variant - kNumIgemm - 1));
         if (y5_try_conv_halo(d, s, bn, &rc)) return rc;
@@ -521,7 +559,7 @@ int y5_launch_conv(const y5_conv_desc& d, hipStream_t s) {
             part.x = static_cast<const f16*>(d.x) + (size_t)b0 * d.h * d.w_in * d.x_ld;
             part.y = static_cast<f16*>(d.y) + (size_t)b0 * d.ho * d.wo * d.y_ld;
             if (d.res) part.res = static_cast<const f16*>(d.res) + (size_t)b0 * d.ho * d.wo * d.res_ld;
-            const int rc = y5_launch_conv(part, s);
+            const int rc = y5_launch_conv(part, s, st);
             if (rc != Y5_OK) return rc;
         }
         return Y5_OK;
@@ -547,6 +585,10 @@ int y5_launch_conv(const y5_conv_desc& d, hipStream_t s) {
     const bool direct = d.ksize == 1 && d.stride == 1;
     a.x_bytes = (int)x_span;
     a.w_bytes = (int)((long long)d.w_rows * d.kpad * 2);
+    if (st) {
+        a.stats = st->partials;
+        a.stats_rows = st->rows; a.stats_c = st->c; a.stats_off = st->off;
+    }
 
     if (d.variant > 0) {
         // a tile reads BN whole weight rows: the packed weights (rows padded to a multiple of 128) must hold them

@@ -46,7 +46,13 @@ static inline int y5_current_device() {
 static inline bool y5_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // Internal launchers (one per kernel family); the extern "C" entry points and the plan replay call these.
-int y5_launch_conv(const y5_conv_desc& d, hipStream_t s);
+// Optional per-channel sums of the stored outputs, accumulated by the convolution's epilogue (im2col kernel family only):
+// partials[r][off + n] += sum, partials[r][c + off + n] += sum of squares over the pixels of M-tile r modulo rows.
+struct Y5ConvStats {
+    float* partials;
+    int rows, c, off;
+};
+int y5_launch_conv(const y5_conv_desc& d, hipStream_t s, const Y5ConvStats* st = nullptr);
 // 3x3 stride-1 halo-tile kernel (conv_halo.hip): returns 1 and sets *rc when it took the convolution.
 int y5_try_conv_halo(const y5_conv_desc& d, hipStream_t s, int force_bn, int* rc);
 int y5_try_conv_ws1x1(const y5_conv_desc& d, hipStream_t s, int which, int* rc);
