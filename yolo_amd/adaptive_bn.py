@@ -7,8 +7,8 @@ What replaces what (reference call sites):
     statistics and moves running_mean / running_var by its momentum (0.03, utils/torch_utils.py:69).
   * the search loop that calls it for every candidate (filter_pruning/02-search_filter_pruning_.py:93-143).
 
-Here each batch runs as: convolution without post-ops (y5_conv_f16) -> per-channel sums (y5_bn_stats_f16) ->
-normalisation coefficients + running-statistics update (y5_bn_finalize_f32) -> normalise + LeakyReLU (+ Bottleneck
+Here each batch runs as: convolution without post-ops that also accumulates the per-channel sums of its output
+(y5_conv_stats_f16; or y5_conv_f16 + a pass of y5_bn_stats_f16 where that measures faster) -> normalisation coefficients + running-statistics update (y5_bn_finalize_f32) -> normalise + LeakyReLU (+ Bottleneck
 shortcut) in place (y5_affine_act_f16).  Activations are NHWC fp16 (weights are rounded to fp16, sums and statistics
 are fp32 / fp64), so the statistics agree with the reference's fp32 forward to fp16 accuracy, not bit for bit; the
 tests state the tolerance.  The Detect layer has no BatchNorm and its train-mode output is discarded by adaptive_BN,
@@ -82,6 +82,10 @@ class _Program:
         self.u8 = u8
         self.keep, self.ops, self.labels = [], [], []
         self.image = torch.zeros(shape, dtype=torch.float16, device=self.device)   # the batch as fp16 NCHW
+        # partial sums that convolutions accumulate for the BatchNorms behind them: one arena, zeroed once per batch
+        total = sum(m.num_features + 16 for m in owner.model.modules() if isinstance(m, nn.BatchNorm2d))
+        self.arena = torch.zeros(self.STAT_ROWS * 2 * total, dtype=torch.float32, device=self.device)
+        self.arena_used = 0
         self._build(owner.model)
 
     # ------------------------------------------------------------------ helpers
@@ -95,8 +99,10 @@ class _Program:
         self.ops.append((fn, args))
         self.labels.append(label)
 
-    def _raw_conv(self, label, x, conv, out):
-        """conv2d without bias, normalisation or activation: out = fp16(conv(x))."""
+    STAT_ROWS = 128   # rows of partial sums a convolution's epilogue spreads its per-tile sums over
+
+    def _conv_desc(self, x, conv, out):
+        """Descriptor of conv2d without bias, normalisation or activation: out = fp16(conv(x))."""
         k, s = _conv_geometry(conv)
         if conv.bias is not None:
             raise Unsupported('convolution with bias in front of a BatchNorm')
@@ -112,46 +118,88 @@ class _Program:
         d.ksize, d.stride, d.pad = k, s, k // 2
         d.kpad, d.w_rows = kpad, rows
         d.act, d.slope = _lib.ACT_NONE, 0.0
-        d.variant = self._tune(d, x)
         self.keep.append(d)
-        self._call('%s conv%dx%d s%d %d->%d @%dx%d v%d' % (label, k, k, s, x.c_log, out.c_log, ho, wo, d.variant),
-                   self.lib.y5_conv_f16, C.byref(d))
+        return d
+
+    def _time(self, call):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        call()
+        e0.record()
+        for _ in range(3):
+            call()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / 3
 
     def _tune(self, d, x):
-        """Fastest compiled tile configuration for this convolution, timed on the real shape (cached per process)."""
+        """(variant, ms) of the fastest tile configuration for the plain convolution and of the fastest one that also
+        accumulates the output's per-channel sums, timed on the real shape (cached per process)."""
         if not self.owner.autotune:
-            return 0
-        key = (d.batch, d.h, d.w_in, d.cin, d.x_ld, d.cout, d.y_ld, d.ksize, d.stride, False, False, False)
+            return (0, 0.0), (0, 0.0)
+        key = ('abn', d.batch, d.h, d.w_in, d.cin, d.x_ld, d.cout, d.y_ld, d.ksize, d.stride)
         if key not in _TUNED:
             x.buf.uniform_(-1.0, 1.0)
             stream = _lib.current_stream()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            best, best_t = 0, float('inf')
+            scratch = torch.zeros(self.STAT_ROWS * 2 * d.cout, dtype=torch.float32, device=self.device)
+            plain, fused = (0, float('inf')), (0, float('inf'))
             for v in range(self.lib.y5_conv_num_variants() + 1):
                 d.variant = v
                 if self.lib.y5_conv_f16(C.byref(d), stream) != 0:
-                    continue
-                e0.record()
-                for _ in range(3):
-                    self.lib.y5_conv_f16(C.byref(d), stream)
-                e1.record()
-                e1.synchronize()
-                if e0.elapsed_time(e1) < best_t:
-                    best, best_t = v, e0.elapsed_time(e1)
-            _TUNED[key] = best
+                    continue  # configuration does not apply to this shape
+                t = self._time(lambda: self.lib.y5_conv_f16(C.byref(d), stream))
+                if t < plain[1]:
+                    plain = (v, t)
+                if v and self.lib.y5_conv_stats_f16(C.byref(d), scratch.data_ptr(), self.STAT_ROWS, d.cout, 0, stream) == 0:
+                    t = self._time(lambda: self.lib.y5_conv_stats_f16(C.byref(d), scratch.data_ptr(), self.STAT_ROWS, d.cout, 0, stream))
+                    if t < fused[1]:
+                        fused = (v, t)
+            _TUNED[key] = (plain, fused)
         return _TUNED[key]
 
-    def _batchnorm(self, label, bn, t, slope, res=None):
-        """Train-mode BatchNorm2d + optional LeakyReLU (+ residual) over tensor t, in place."""
+    def _fuse_stats(self, d, x):
+        """Whether this convolution should accumulate the statistics itself: when its best accumulating configuration costs
+        less than the best plain one plus a separate pass over the output (>= 6 us, ~3 TB/s)."""
+        if not self.owner.fuse_stats:
+            return False
+        plain, fused = self._tune(d, x)
+        if not self.owner.autotune:
+            return True
+        stats_ms = max(6e-3, d.batch * d.ho * d.wo * d.cout * 2 / 3.0e9)
+        return fused[1] <= plain[1] + stats_ms
+
+    def _emit_raw(self, label, d, x, stat=None):
+        """Record the convolution; stat = (partials pointer, rows, total channels, channel offset) makes it accumulate."""
+        plain, fused = self._tune(d, x)
+        d.variant = fused[0] if stat else plain[0]
+        text = '%s conv%dx%d s%d %d->%d @%dx%d v%d' % (label, d.ksize, d.ksize, d.stride, x.c_log, d.cout, d.ho, d.wo, d.variant)
+        if stat:
+            self._call(text + ' +sums', self.lib.y5_conv_stats_f16, C.byref(d), *stat)
+        else:
+            self._call(text, self.lib.y5_conv_f16, C.byref(d))
+
+    def _stat_slice(self, c_pad):
+        n = self.STAT_ROWS * 2 * c_pad
+        if self.arena_used + n > self.arena.numel():
+            raise RuntimeError('adaptive_bn: statistics arena too small')
+        part = self.arena[self.arena_used:self.arena_used + n]
+        self.arena_used += n
+        return part
+
+    def _batchnorm(self, label, bn, t, slope, res=None, part=None):
+        """Train-mode BatchNorm2d + optional LeakyReLU (+ residual) over tensor t, in place.  part: the partial sums the
+        producing convolutions accumulated (STAT_ROWS rows); None = a pass over t computes them."""
         st = self.owner.bn_state(bn, t.segs)
         pixels = t.batch * t.h * t.w
-        rows = self.lib.y5_bn_stats_rows(pixels, t.c_pad)
-        if rows <= 0:
-            raise Unsupported('BatchNorm over %d channels' % t.c_pad)
-        part = st.partials.get(pixels)
         if part is None:
-            part = st.partials[pixels] = torch.zeros(rows * 2 * t.c_pad, dtype=torch.float32, device=self.device)
-        self._call(label + ' bn stats', self.lib.y5_bn_stats_f16, t.ptr, t.ld, pixels, t.c_pad, part.data_ptr())
+            rows = self.lib.y5_bn_stats_rows(pixels, t.c_pad)
+            if rows <= 0:
+                raise Unsupported('BatchNorm over %d channels' % t.c_pad)
+            part = st.partials.get(pixels)
+            if part is None:
+                part = st.partials[pixels] = torch.zeros(rows * 2 * t.c_pad, dtype=torch.float32, device=self.device)
+            self._call(label + ' bn stats', self.lib.y5_bn_stats_f16, t.ptr, t.ld, pixels, t.c_pad, part.data_ptr())
+        else:
+            rows = self.STAT_ROWS
         self.ops.append((self._finalize, (st, part, rows, pixels)))
         self.labels.append(label + ' bn finalize')
         act = _lib.ACT_NONE if slope is None else _lib.ACT_LEAKY
@@ -180,8 +228,10 @@ class _Program:
             raise Unsupported('Conv with its BatchNorm folded away (Model.fuse) has no statistics to recalibrate')
         if res is not None and (res.c_pad, res.h, res.w) != (out.c_pad, out.h, out.w):
             raise Unsupported('residual shape mismatch')
-        self._raw_conv(label, x, m.conv, out)
-        self._batchnorm(label, m.bn, out, self._slope(m.act), res)
+        d = self._conv_desc(x, m.conv, out)
+        part = self._stat_slice(out.c_pad) if self._fuse_stats(d, x) else None
+        self._emit_raw(label, d, x, None if part is None else (part.data_ptr(), self.STAT_ROWS, out.c_pad, 0))
+        self._batchnorm(label, m.bn, out, self._slope(m.act), res, part)
 
     def _block_out(self, x, conv, s=1):
         c = conv.out_channels
@@ -203,9 +253,13 @@ class _Program:
             t = self._bottleneck('%s.m%d' % (label, bi), b, t)
         c3, c2 = m.cv3.out_channels, m.cv2.out_channels
         cat = self._new(x.h, x.w, [(c3, pad8(c3)), (c2, pad8(c2))])
-        self._raw_conv(label + '.cv3', t, m.cv3, cat.slice(0, [(c3, pad8(c3))]))
-        self._raw_conv(label + '.cv2', x, m.cv2, cat.slice(pad8(c3), [(c2, pad8(c2))]))
-        self._batchnorm(label, m.bn, cat, self._slope(m.act))
+        d3 = self._conv_desc(t, m.cv3, cat.slice(0, [(c3, pad8(c3))]))
+        d2 = self._conv_desc(x, m.cv2, cat.slice(pad8(c3), [(c2, pad8(c2))]))
+        part = self._stat_slice(cat.c_pad) if self._fuse_stats(d3, t) and self._fuse_stats(d2, x) else None
+        stat = (lambda off: None) if part is None else (lambda off: (part.data_ptr(), self.STAT_ROWS, cat.c_pad, off))
+        self._emit_raw(label + '.cv3', d3, t, stat(0))
+        self._emit_raw(label + '.cv2', d2, x, stat(pad8(c3)))
+        self._batchnorm(label, m.bn, cat, self._slope(m.act), part=part)
         out = self._block_out(cat, m.cv4.conv)
         self._conv_block(label + '.cv4', m.cv4, cat, out)
         return out
@@ -297,6 +351,8 @@ class _Program:
             _lib.check(self.lib.y5_normalize_u8_f16(inputs.data_ptr(), self.image.data_ptr(), inputs.numel(), stream))
         else:
             self.image.copy_(inputs)
+        if self.arena_used:
+            self.arena[:self.arena_used].zero_()
         for (fn, args), label in zip(self.ops, self.labels):
             rc = fn(*args, stream)
             if rc != 0:
@@ -307,8 +363,11 @@ class Recalibrator:
     """Runs train-mode forwards of `model` (a models.yolo.Model on a GPU) on the HIP kernels and keeps the moved BatchNorm
     statistics; finish() writes them into the modules."""
 
-    def __init__(self, model, autotune=True):
+    def __init__(self, model, autotune=True, fuse_stats=True):
+        """autotune: time the compiled tile configurations per layer; fuse_stats: let convolutions accumulate the sums of
+        their output where that is faster than a separate pass."""
         self.model = model
+        self.fuse_stats = fuse_stats
         self.lib = _lib.lib()
         self.device = next(model.parameters()).device
         if self.device.type != 'cuda':
