@@ -1,5 +1,7 @@
+"""Diagnostic: adaptive-BN statistics of the HIP path against the fp32 oracle and against the oracle restated with fp16
+activations, per model and input size (worst error over all BatchNorm channels)."""
 import os, sys, torch, yaml
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tests import util
 from oracle import y5ref
 from yolo_amd.adaptive_bn import Recalibrator
