@@ -174,3 +174,68 @@ def test_test_time_augmentation_runs_on_the_engine(dev):
     x = torch.rand(1, 3, 128, 128).half().to(dev)
     y, none = model(x, augment=True)
     assert none is None and calls(model) == 3 and y.shape[0] == 1 and y.shape[2] == 85
+
+
+def test_folded_upsample_concat_equals_the_materialised_plan(dev, monkeypatch):
+    """nn.Upsample -> Concat read only by 1x1 convolutions is folded into those convolutions (y5_conv_cat2_f16); with
+    Y5_CAT2_FUSE=0 the plan upsamples and concatenates for real.  Same arithmetic, fp32 summation order aside."""
+    model = util.build_model('yolov5s')
+    util.randomize_bn(model, 6)
+    model = model.eval().half().to(dev)
+    x = torch.rand(2, 3, 128, 192, generator=torch.Generator().manual_seed(3)).half().to(dev)
+    folded = engine.Plan(model, x)
+    monkeypatch.setenv('Y5_CAT2_FUSE', '0')
+    plain = engine.Plan(model, x)
+    try:
+        assert sum('up2x' in label for label in folded.labels) == 2 and not any('upsample' in label for label in folded.labels)
+        assert sum('upsample' in label for label in plain.labels) == 2 and not any('up2x' in label for label in plain.labels)
+        z0, xs0 = folded.run(x)
+        z1, xs1 = plain.run(x)
+        torch.cuda.synchronize()
+    finally:
+        folded.close()
+        plain.close()
+    for a, b in zip(xs0, xs1):
+        agree(a, b, 0.60)
+    agree(z0, z1, 0.90)
+
+
+def test_concat_with_a_3x3_reader_is_built(dev):
+    """The fold applies only where every reader is a 1x1 convolution: a graph whose Concat feeds a 3x3 Conv keeps the
+    upsample kernel and still matches torch's kernels."""
+    from yolo_amd.models.yolo import Model
+    cfg = {'nc': 3, 'depth_multiple': 1.0, 'width_multiple': 1.0, 'anchors': [[10, 13, 16, 30, 33, 23]],
+           'backbone': [[-1, 1, 'Focus', [64, 3]], [-1, 1, 'Conv', [64, 3, 2]], [-1, 1, 'Conv', [64, 3, 2]]],
+           'head': [[-1, 1, 'nn.Upsample', [None, 2, 'nearest']], [[-1, 1], 1, 'Concat', [1]], [-1, 1, 'Conv', [64, 3, 1]],
+                    [[5], 1, 'Detect', ['nc', 'anchors']]]}
+    torch.manual_seed(0)
+    model = util.quiet(Model, cfg)
+    util.randomize_bn(model, 2)
+    model = model.eval().half().to(dev)
+    x = torch.rand(2, 3, 64, 96, generator=torch.Generator().manual_seed(4)).half().to(dev)
+    z, xs = model(x)
+    assert calls(model) == 1
+    plan = engine.Plan(model, x)
+    try:
+        assert any('upsample' in label for label in plan.labels) and not any('up2x' in label for label in plan.labels)
+    finally:
+        plan.close()
+    with engine.disabled():
+        zt, _ = model(x)
+    agree(z, zt, 0.80)
+    # the same graph with a 1x1 reader folds
+    cfg['head'][2] = [-1, 1, 'Conv', [64, 1, 1]]
+    torch.manual_seed(0)
+    model = util.quiet(Model, cfg)
+    util.randomize_bn(model, 2)
+    model = model.eval().half().to(dev)
+    z, xs = model(x)
+    assert calls(model) == 1
+    plan = engine.Plan(model, x)
+    try:
+        assert any('up2x' in label for label in plan.labels) and not any('upsample' in label for label in plan.labels)
+    finally:
+        plan.close()
+    with engine.disabled():
+        zt, _ = model(x)
+    agree(z, zt, 0.80)

@@ -130,7 +130,6 @@ class Cat2(Act):
     def __init__(self, a, b):
         super().__init__(None, 0, 0, b.batch, b.h, b.w, list(a.segs) + list(b.segs))
         self.a, self.b = a, b
-        self.real = None  # the materialised tensor, if some consumer needed one
 
 
 class Unsupported(Exception):
@@ -242,10 +241,9 @@ class Plan:
             raise Unsupported('conv output slice mismatch')
         cat2 = None
         if isinstance(x, Cat2):
-            if k == 1 and s == 1 and image is None and self._defer is None and x.real is None:
-                cat2 = x
-            else:
-                x = self._materialise(x)
+            if not (k == 1 and s == 1 and image is None and self._defer is None):
+                raise Unsupported('a folded Upsample + Concat read by something other than a 1x1 convolution')  # pass 2 of _build rules it out
+            cat2 = x
         ho = (x.h + 2 * (k // 2) - k) // s + 1
         wo = (x.w + 2 * (k // 2) - k) // s + 1
         if (ho, wo) != (out.h, out.w):
@@ -298,19 +296,6 @@ class Plan:
         d.variant = self._tune(d, x)
         _lib.check(self.lib.y5_plan_add_conv(self.handle, C.byref(d)))
         self.labels.append('%s v%d' % (text, d.variant))
-
-    def _materialise(self, cat):
-        """The real tensor behind a Cat2, built (once) for a consumer that cannot read the two sources itself."""
-        if cat.real is None:
-            a, b = cat.a, cat.b
-            real = self._new_act(b.batch, b.h, b.w, cat.segs)
-            _lib.check(self.lib.y5_plan_add_upsample2x(self.handle, a.ptr, a.ld, real.ptr, real.ld, a.batch, a.h, a.w, a.c_pad, 0))
-            self.labels.append('upsample2x nearest (concat materialised)')
-            _lib.check(self.lib.y5_plan_add_copy_channels(self.handle, b.ptr, b.ld, real.ptr + 2 * a.c_pad, real.ld,
-                                                           b.batch * b.h * b.w, b.c_pad))
-            self.labels.append('copy part (concat materialised)')
-            cat.real = real
-        return cat.real
 
     def _tune_cat2(self, d, cat):
         """Fastest tile configuration of the two-source 1x1 convolution for this shape (timed, cached per process)."""
