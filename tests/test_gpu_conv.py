@@ -150,6 +150,10 @@ VARIANT_SHAPES = [
     (2, 160, 320, 12, 20, 3, 1),
     (2, 80, 96, 20, 24, 3, 1),
     (1, 40, 72, 17, 33, 3, 2),
+    # more tiles than resident workgroups: the persistent variants walk several tiles each
+    (32, 64, 64, 80, 80, 3, 1),
+    (16, 128, 200, 56, 72, 1, 1),
+    (24, 32, 48, 96, 64, 3, 2),
 ]
 
 

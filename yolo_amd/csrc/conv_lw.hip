@@ -349,6 +349,265 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_lw_kernel(const Conv
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Persistent form of the plain convolution above: a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...  Its
+// loader waves run one tile ahead of the epilogue: as soon as the consumers have read the last K-step of tile i
+// (barrier F) the loaders fill the first ring stages of tile i+1 while the consumers apply the post-ops, stage the
+// tile in its own LDS region (not the ring) and store it.  Only consumer waves store.  Barrier sequence per tile, the
+// same for both roles: nk K-step barriers, F, E (tile staged); a loader passes E of tile i after it has issued the
+// prologue of tile i+1, without waiting for those DMAs.
+template <int BM, int BN, int WM, int WN, int NL, int S, int BK>
+struct LwpCfg {
+    typedef LwCfg<BM, BN, WM, WN, NL, S, BK> Base;
+    static constexpr int EPI0 = S * Base::STAGE_BYTES;          // staged output tile, behind the ring
+    static constexpr int PRM0 = EPI0 + BM * Base::EP;           // per-channel parameters
+    static constexpr int SMEM = PRM0 + 3 * BN * 4;
+};
+
+__device__ __forceinline__ void wait_lgkm_and_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int BM, int BN, int WM, int WN, int NL, int S, int BK, bool DIRECT>
+__global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_lwp_kernel(const ConvArgs a) {
+    typedef LwCfg<BM, BN, WM, WN, NL, S, BK> Cfg;
+    typedef LwpCfg<BM, BN, WM, WN, NL, S, BK> PCfg;
+    constexpr int NWC = WM * WN;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int RM = WTM / 32, RN = WTN / 32;
+    constexpr int ROW_BYTES = BK * 2;
+    constexpr int CPRW = BK / 8;
+    constexpr int RPW = 64 / CPRW;
+    constexpr int A_PIECES = BM / RPW, B_PIECES = BN / RPW;
+    static_assert(A_PIECES % NL == 0 && B_PIECES % NL == 0, "loader waves share the stage evenly");
+    constexpr int A_CH = A_PIECES / NL, B_CH = B_PIECES / NL, LPS = A_CH + B_CH;
+    constexpr int STAGE_BYTES = Cfg::STAGE_BYTES, EP = Cfg::EP;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    unsigned char* etile = smem + PCfg::EPI0;
+    float* prm = reinterpret_cast<float*>(smem + PCfg::PRM0);
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int nk = a.nk;
+    const int ntiles = a.tiles_total;
+
+    if (wave >= NWC) {
+        // ------------------------------------------------------------------ loader waves
+        const int lw = wave - NWC;
+        constexpr unsigned OOB = 0x80000000u;
+        const BufRsrc xr = make_rsrc(a.x, a.x_bytes), wr = make_rsrc(a.w, a.w_bytes);
+        bool first = true;
+        for (int it = blockIdx.x; it < ntiles; it += gridDim.x) {
+            const int tile = xcd_remap(it, ntiles);
+            const int mt = tile / a.tiles_n, nt = tile - mt * a.tiles_n;
+            const int m0 = mt * BM, n0 = nt * BN;
+            int abase[A_CH];
+            unsigned vmask[A_CH];
+            int kc8[A_CH];
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) {
+                const int row = (lw + NL * i) * RPW + lane / CPRW;
+                const int kc = (lane % CPRW) ^ ((BK == 64) ? ((row >> 1) & 7) : ((row >> 2) & 3));
+                kc8[i] = kc * 8;
+                const int m = m0 + row;
+                const bool mvalid = m < a.M;
+                const unsigned mm = mvalid ? (unsigned)m : 0u;
+                vmask[i] = 0;
+                if (DIRECT) {
+                    abase[i] = (int)((mm * (unsigned)a.x_ld + kc * 8) * 2u);
+                    vmask[i] = mvalid ? 1u : 0u;
+                } else {
+                    const unsigned b = fdiv(mm, a.div_hw);
+                    const unsigned rem = mm - b * (unsigned)(a.Ho * a.Wo);
+                    const unsigned oy = fdiv(rem, a.div_wo), ox = rem - oy * (unsigned)a.Wo;
+                    const int hi0 = (int)oy * a.stride - a.pad, wi0 = (int)ox * a.stride - a.pad;
+                    abase[i] = (((int)b * a.H + hi0) * a.W + wi0) * a.x_ld * 2 + kc * 16;
+#pragma unroll
+                    for (int tp = 0; tp < 9; ++tp) {
+                        const int hi = hi0 + tp / 3, wi = wi0 + tp % 3;
+                        if (mvalid && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W) vmask[i] |= 1u << tp;
+                    }
+                }
+            }
+            unsigned wbase[B_CH];
+#pragma unroll
+            for (int i = 0; i < B_CH; ++i) {
+                const int row = (lw + NL * i) * RPW + lane / CPRW;
+                const int kc = (lane % CPRW) ^ ((BK == 64) ? ((row >> 1) & 7) : ((row >> 2) & 3));
+                wbase[i] = ((unsigned)(n0 + row) * (unsigned)a.w_ld + kc * 8) * 2u;
+            }
+            int tap = 0, c0 = 0, kbase = 0;
+            auto issue = [&](int stage) {
+                int off = kbase * 2;
+                unsigned bit = 1u;
+                if (!DIRECT) {
+                    const int r = (tap * 11) >> 5, q = tap - 3 * r;
+                    off = ((r * a.W + q) * a.x_ld + c0) * 2;
+                    bit = 1u << tap;
+                }
+                const int koff = (DIRECT ? kbase : tap * a.Cin + c0) * 2;
+                unsigned char* base = smem + stage * STAGE_BYTES + lw * 1024;
+#pragma unroll
+                for (int i = 0; i < A_CH; ++i) {
+                    const bool ok = DIRECT ? (vmask[i] && kbase + kc8[i] < a.K) : ((vmask[i] & bit) != 0 && c0 + kc8[i] < a.Cin);
+                    const unsigned vo = ok ? (unsigned)(abase[i] + off) : OOB;
+                    buf_dma16(xr, (lds_ptr)(base + i * (NL * 1024)), vo, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < B_CH; ++i)
+                    buf_dma16(wr, (lds_ptr)(base + BM * ROW_BYTES + i * (NL * 1024)), wbase[i] + (unsigned)koff, 0);
+                kbase += BK;
+                if (!DIRECT) {
+                    c0 += BK;
+                    if (c0 >= a.Cin) {
+                        c0 = 0;
+                        ++tap;
+                    }
+                }
+            };
+            // the ring is free: every consumer passed barrier F of the previous tile
+#pragma unroll
+            for (int s = 0; s < S - 1; ++s)
+                if (s < nk) issue(s);
+            if (!first) wait_vm_and_barrier((S - 1) * LPS);  // barrier E of the previous tile; the prologue stays in flight
+            first = false;
+            for (int kt = 0; kt < nk; ++kt) {
+                int ahead = nk - 1 - kt;
+                if (ahead > S - 2) ahead = S - 2;
+                wait_vm_and_barrier(ahead * LPS);
+                if (kt + S - 1 < nk) issue((kt + S - 1) % S);
+            }
+            wait_vm_and_barrier(0);  // F
+        }
+        if (!first) wait_vm_and_barrier(0);  // barrier E of the last tile
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumer waves
+    const int wm = wave % WM, wn = wave / WM;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int sw = (BK == 64) ? ((lr >> 1) & 7) : ((lr >> 2) & 3);
+    const bool has_bias = a.bias != nullptr, has_scale = a.scale != nullptr;
+    constexpr int NTC = 64 * NWC;  // consumer threads: they alone stage and store the tile
+    constexpr int CPR = BN / 8;
+    constexpr int RPP = NTC / CPR;
+    static_assert(NTC % CPR == 0 && NTC >= BN, "consumer threads cover whole tile rows and the tile's channels");
+    const int cc = t % CPR, rr = t / CPR;
+    for (int it = blockIdx.x; it < ntiles; it += gridDim.x) {
+        const int tile = xcd_remap(it, ntiles);
+        const int mt = tile / a.tiles_n, nt = tile - mt * a.tiles_n;
+        const int m0 = mt * BM, n0 = nt * BN;
+        // this tile's per-channel parameters: the previous tile's were last read before its barrier E; published by the
+        // K-step barriers below
+        epi_store(prm, epi_fetch(a, n0, t, BN), t, BN);
+        f32x16 acc[RN][RM];
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
+        for (int kt = 0; kt < nk; ++kt) {
+            wait_lgkm_and_barrier();  // own fragment reads of step kt-1 are done; the loaders saw step kt land
+            const unsigned char* A = smem + (kt % S) * STAGE_BYTES;
+            const unsigned char* B = A + BM * ROW_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                const int coff = ((2 * ks + lh) ^ sw) << 4;
+                f16x8 xf[RM], wf[RN];
+#pragma unroll
+                for (int i = 0; i < RM; ++i)
+                    xf[i] = *reinterpret_cast<const f16x8*>(A + (wm * WTM + i * 32 + lr) * ROW_BYTES + coff);
+#pragma unroll
+                for (int j = 0; j < RN; ++j)
+                    wf[j] = *reinterpret_cast<const f16x8*>(B + (wn * WTN + j * 32 + lr) * ROW_BYTES + coff);
+#pragma unroll
+                for (int j = 0; j < RN; ++j)
+#pragma unroll
+                    for (int i = 0; i < RM; ++i)
+                        acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], xf[i], acc[j][i], 0, 0, 0);
+            }
+        }
+        wait_lgkm_and_barrier();  // F: every consumer is done reading the ring
+#pragma unroll
+        for (int j = 0; j < RN; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nl = wn * WTN + j * 32 + 8 * g + 4 * lh;
+                if (n0 + nl < a.Cout) {
+#pragma unroll
+                    for (int i = 0; i < RM; ++i) {
+                        const f32x4 v = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
+                        const int ml = wm * WTM + i * 32 + lr;
+                        *reinterpret_cast<f16x4*>(etile + ml * EP + nl * 2) = post_op4_lds(v, nl, prm, BN, has_bias, has_scale, a.slope);
+                    }
+                }
+            }
+        }
+        wait_lgkm_and_barrier();  // E: the tile is staged
+        const int n = n0 + cc * 8;
+        if (n < a.Cout) {
+#pragma unroll
+            for (int p = 0; p < (BM + RPP - 1) / RPP; ++p) {
+                const int row = rr + p * RPP;
+                const int m = m0 + row;
+                if (row < BM && m < a.M) {
+                    f16x8 v = *reinterpret_cast<const f16x8*>(etile + row * EP + cc * 16);
+                    if (a.res) v += *reinterpret_cast<const f16x8*>(a.res + (size_t)m * a.res_ld + n);
+                    *reinterpret_cast<f16x8*>(a.y + (size_t)m * a.y_ld + n) = v;
+                }
+            }
+        }
+    }
+}
+
+int y5_cu_count() {
+    static std::atomic<int> cached[64];
+    const int dev = y5_current_device();
+    int n = cached[dev].load();
+    if (n == 0) {
+        int real = 0;
+        if (hipGetDevice(&real) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, real) != hipSuccess || n <= 0) n = 256;
+        cached[dev].store(n);
+    }
+    return n;
+}
+
+template <int BM, int BN, int WM, int WN, int NL, int S, int BK>
+int launch_lwp(const ConvArgs& a0, bool direct, bool tail, hipStream_t s) {
+    typedef LwpCfg<BM, BN, WM, WN, NL, S, BK> PCfg;
+    static_assert(PCfg::SMEM <= 160 * 1024, "ring + staged tile must fit the CU's LDS");
+    if (tail) return y5_fail(Y5_EINVAL, "conv chain: the persistent variants run single convolutions only");
+    ConvArgs a = a0;
+    const long long tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = (a.Cout + BN - 1) / BN;
+    a.nk = direct ? (a.K + BK - 1) / BK : 9 * ((a.Cin + BK - 1) / BK);
+    const long long total = tiles_m * a.tiles_n;
+    if (total <= 0 || total > 0x7fffffffLL) return y5_fail(Y5_EINVAL, "conv: tile count %lld out of range", total);
+    a.tiles_total = (int)total;
+    static std::atomic<unsigned long long> attr_set{0};
+    const unsigned long long bit = 1ull << y5_current_device();
+    if (!(attr_set.load() & bit)) {
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lwp_kernel<BM, BN, WM, WN, NL, S, BK, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, PCfg::SMEM));
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lwp_kernel<BM, BN, WM, WN, NL, S, BK, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, PCfg::SMEM));
+        attr_set.fetch_or(bit);
+    }
+    // as many workgroups as stay resident at once (LDS and the 2048 threads of a CU), each walking its share of tiles
+    constexpr int NT = 64 * (WM * WN + NL);
+    int per_cu = (160 * 1024) / PCfg::SMEM;
+    if (per_cu > 2048 / NT) per_cu = 2048 / NT;
+    if (per_cu < 1) per_cu = 1;
+    long long grid = (long long)y5_cu_count() * per_cu;
+    if (grid > total) grid = total;
+    if (direct)
+        hipLaunchKernelGGL((conv_lwp_kernel<BM, BN, WM, WN, NL, S, BK, true>), dim3((unsigned)grid), dim3(NT), PCfg::SMEM, s, a);
+    else
+        hipLaunchKernelGGL((conv_lwp_kernel<BM, BN, WM, WN, NL, S, BK, false>), dim3((unsigned)grid), dim3(NT), PCfg::SMEM, s, a);
+    Y5_LAUNCH_CHECK("conv_lwp_kernel");
+    return Y5_OK;
+}
+
 template <int BM, int BN, int WM, int WN, int NL, int S, int BK>
 int launch_lw(const ConvArgs& a0, bool direct, bool tail, hipStream_t s) {
     typedef LwCfg<BM, BN, WM, WN, NL, S, BK> Cfg;
@@ -395,13 +654,19 @@ struct LwVariant {
     int (*launch)(const ConvArgs&, bool, bool, hipStream_t);
 };
 #define Y5_LW(BM, BN, WM, WN, NL, S, BK) {BN, BK, &launch_lw<BM, BN, WM, WN, NL, S, BK>}
+#define Y5_LWP(BM, BN, WM, WN, NL, S, BK) {BN, BK, &launch_lwp<BM, BN, WM, WN, NL, S, BK>}
 const LwVariant kLw[] = {
     Y5_LW(256, 128, 4, 2, 8, 2, 64), Y5_LW(256, 128, 4, 2, 8, 3, 64), Y5_LW(256, 128, 4, 2, 8, 3, 32),
     Y5_LW(128, 128, 2, 2, 4, 2, 64), Y5_LW(128, 128, 2, 2, 4, 3, 32), Y5_LW(128, 128, 2, 4, 8, 3, 64),
     Y5_LW(256, 64, 4, 2, 8, 3, 64),  Y5_LW(128, 64, 2, 2, 4, 3, 64),  Y5_LW(64, 64, 2, 2, 4, 3, 64),
     Y5_LW(64, 128, 2, 2, 4, 3, 64),  Y5_LW(256, 256, 2, 4, 4, 2, 64), Y5_LW(256, 256, 2, 4, 4, 3, 32),
+    // persistent workgroups (conv_lwp_kernel): single convolutions only
+    Y5_LWP(256, 128, 4, 2, 8, 3, 32), Y5_LWP(128, 128, 2, 2, 4, 2, 64), Y5_LWP(128, 128, 2, 2, 4, 3, 32),
+    Y5_LWP(128, 128, 2, 4, 8, 3, 64), Y5_LWP(128, 64, 2, 2, 4, 3, 64),  Y5_LWP(64, 64, 2, 2, 4, 3, 64),
+    Y5_LWP(256, 64, 4, 2, 8, 3, 64),  Y5_LWP(64, 128, 2, 2, 4, 3, 64),
 };
 #undef Y5_LW
+#undef Y5_LWP
 
 constexpr int DETECT_EXTRA = (TP + 1) * Y5_MAX_ANCHORS * 4 * (int)sizeof(f16);  // decoded box slots behind the parameters
 
