@@ -22,6 +22,32 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 PEAK_MFMA_TFLOPS = 2500.0   # dense fp16 MFMA peak of one MI355X
 PEAK_HBM_GBS = 8000.0       # HBM3E peak of one MI355X
+DECODE_BYTES_PER_IMAGE_640 = 2 * 25200 * 85 * 2.0   # Detect decode at 640x640, nc = 80: head tensor read + z written, fp16
+
+
+def reference_layer_work(model, x):
+    """(bytes, FLOPs) of one forward of the batch x with every nn.Conv2d of the graph as its own kernel: fp16 input +
+    output per image, weights once, 2 FLOP per multiply-add (Detect's convolutions included; BatchNorm folded,
+    activations free).  Shapes come from forward hooks on the torch modules for ONE image (the hooks keep the HIP engine
+    out of that forward), outside every timed region."""
+    import torch.nn as nn
+    recs = []
+    hooks = [m.register_forward_hook(lambda m, i, o: recs.append((m, tuple(i[0].shape), tuple(o.shape))))
+             for m in model.modules() if isinstance(m, nn.Conv2d)]
+    try:
+        with torch.no_grad():
+            one = x[:1]
+            model(one.half() / 255.0 if one.dtype is torch.uint8 else one)
+    finally:
+        for h in hooks:
+            h.remove()
+    act = wts = flops = 0
+    for m, i, o in recs:
+        act += 2 * (i[1] * i[2] * i[3] + o[1] * o[2] * o[3])
+        wts += 2 * m.weight.numel()
+        flops += 2 * o[1] * o[2] * o[3] * m.weight[0].numel()
+    b = x.shape[0]
+    return float(act * b + wts), float(flops * b)
 
 
 def build_model(name, device):
@@ -163,7 +189,12 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         nms_ms = e0.elapsed_time(e1) / args.profile_passes
-        conv_bytes = sum(a['bytes'] for a in conv)
+        plan_bytes = sum(a['bytes'] for a in conv)   # what the recorded (fused) launches need at minimum
+        # ALGORITHMIC bytes: the graph's own layer list, every nn.Conv2d as one kernel (fp16 input + output + weights) -
+        # the un-fused figure the graph's arithmetic intensity is quoted on - plus the decode's read + write of the head
+        # tensor when the Detect kernels (conv + decode) are in the timed set.  Fusing layers lowers the time, not this.
+        ref_bytes, ref_flops = reference_layer_work(model, x)
+        conv_bytes = ref_bytes + (args.batch * DECODE_BYTES_PER_IMAGE_640 * (x.shape[2] * x.shape[3]) / (640.0 * 640.0) if det else 0.0)
         tflops = conv_flops / (conv_ms * 1e-3) / 1e12
         gbs = conv_bytes / (conv_ms * 1e-3) / 1e9
         # which roof binds the convolution work of this model: its FLOP/byte against the machine's
@@ -180,7 +211,8 @@ def main():
                     'achieved': round(gbs if hbm_bound else tflops, 2), 'peak': PEAK_HBM_GBS if hbm_bound else PEAK_MFMA_TFLOPS,
                     'unit': 'GB/s' if hbm_bound else 'TFLOP/s',
                     'frac': round(gbs / PEAK_HBM_GBS if hbm_bound else tflops / PEAK_MFMA_TFLOPS, 4), 'traffic': traffic,
-                    'bytes_per_forward': conv_bytes, 'flops_per_forward': conv_flops, 'ms_per_forward': round(conv_ms, 4),
+                    'bytes_per_forward': conv_bytes, 'bytes_basis': 'every Conv2d of the graph as one kernel (in + out + weights, fp16)' + (' + decode read/write of the head' if det else ''),
+                    'plan_bytes_per_forward': plan_bytes, 'flops_per_forward': conv_flops, 'layer_list_flops': ref_flops, 'ms_per_forward': round(conv_ms, 4),
                     'mfma_tflops': round(tflops, 2), 'mfma_frac': round(tflops / PEAK_MFMA_TFLOPS, 4),
                     'per_op_event_scale': round(event_scale, 4)}
         record = {
