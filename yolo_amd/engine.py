@@ -377,7 +377,7 @@ class Plan:
         x.buf.uniform_(-1.0, 1.0)
         stream = _lib.current_stream()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        best, best_t = 0, float('inf')
+        timed = []
         for v in range(self.lib.y5_conv_num_variants() + 1):
             d.variant = v
             if self.lib.y5_conv_f16(C.byref(d), stream) != 0:
@@ -387,11 +387,21 @@ class Plan:
                 self.lib.y5_conv_f16(C.byref(d), stream)
             e1.record()
             e1.synchronize()
-            t = e0.elapsed_time(e1)
+            timed.append((e0.elapsed_time(e1) / 4, v))
+        # the few fastest are within timing noise of each other after four launches: time those again, longer
+        best, best_t = 0, float('inf')
+        for _, v in sorted(timed)[:3]:
+            d.variant = v
+            e0.record()
+            for _ in range(12):
+                self.lib.y5_conv_f16(C.byref(d), stream)
+            e1.record()
+            e1.synchronize()
+            t = e0.elapsed_time(e1) / 12
             if t < best_t:
                 best, best_t = v, t
         _TUNED[key] = best
-        _TUNED_MS[key] = best_t / 4
+        _TUNED_MS[key] = best_t
         return best
 
     @staticmethod
