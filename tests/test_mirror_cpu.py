@@ -132,3 +132,14 @@ def test_pruned_shapes_run_on_the_module_walk():
     assert list(out.shape) == z['out_shape'].tolist()
     odd = [m.out_channels for m in model.modules() if isinstance(m, torch.nn.Conv2d) and m.out_channels % 8]
     assert len(odd) > 40  # the plan really has irregular widths
+
+
+def test_adaptive_bn_has_no_cpu_path():
+    """The recalibration forward runs on the HIP kernels only: a model on the CPU is refused, not silently run elsewhere."""
+    import pytest
+    from yolo_amd.adaptive_bn import Recalibrator, adaptive_bn
+    model = util.build_model('yolov5s')
+    with pytest.raises(RuntimeError):
+        Recalibrator(model)
+    with pytest.raises(RuntimeError):
+        adaptive_bn(model, [torch.zeros(1, 3, 64, 64, dtype=torch.uint8)])
