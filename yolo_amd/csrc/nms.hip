@@ -237,6 +237,7 @@ __global__ __launch_bounds__(SORT_THREADS) void nms_sort_kernel(u64* __restrict_
 //   merge_chunks(k)  passes j = 1024 .. 1 of stage k inside each chunk, in LDS
 // Images beyond CHUNK_MAX_P2 keys are left to nms_sort_kernel (min_p2 = 2 * CHUNK_MAX_P2).
 constexpr int CHUNK = 2048, CHUNK_LOG2 = 11, CHUNK_MAX_P2 = 16384;
+static_assert(CHUNK == 2 * 1024 && (1 << CHUNK_LOG2) == CHUNK, "the chunk kernels do one compare-exchange per thread of a 1024-thread workgroup");
 
 __device__ __forceinline__ int padded_size(const int* counters, int b, int cap) {
     int n = counters[b];
