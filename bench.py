@@ -1,12 +1,16 @@
 """Benchmark of the hot path: yolov5s 640x640 fp16, conv forward + Detect decode + NMS, images/s.
 
-  python bench.py [--gpus N --steps K --warmup W]          (N=1: plain process)
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N>1: one rank per GPU)
+  python bench.py [--gpus N --steps K --warmup W]
+      N = 1: one process.  N > 1 from a plain call: this process starts N rank processes (one per GPU, before it has
+      touched a GPU itself) and passes rank 0's JSON line on; under torch.distributed.run (WORLD_SIZE set) it IS a rank.
+  python bench.py --gpus N --model yolov5x --global-batch 256
+      the sharded form: the global batch is split into contiguous slices (128 / 64 / 32 images per GPU at N = 2 / 4 / 8),
+      "scaling": "strong".  Without --global-batch every GPU gets --batch images (weak scaling).
 
 One step = one batch of synthetic images (already resident in HBM as fp16 NCHW) through the HIP launch
 plan (all convs, SPP, upsample/concat, head convs, decode) and the batched NMS kernels, ending with padded
-detections + counts on the device; with N>1 each rank processes its own batch (weak scaling) and the step
-ends with the RCCL all_gather of the detection blocks.  Rank 0 prints one JSON line.
+detections + counts on the device; with N>1 the step ends with the all_gather of the detection blocks (RCCL; gloo
+when rehearsing more ranks than there are GPUs).  Rank 0 prints one JSON line.
 """
 import argparse
 import json
@@ -50,10 +54,10 @@ def reference_layer_work(model, x):
     return float(act * b + wts), float(flops * b)
 
 
-def build_model(name, device):
+def build_model(name, device, head_gain=2.0):
     import util  # tests/util.py: seeded construction + BatchNorm calibration + head gain (synthetic weights)
     model = util.build_model(name, seed=0)
-    util.calibrate(model, seed=1, size=640, head_gain=2.0)
+    util.calibrate(model, seed=1, size=640, head_gain=head_gain)
     fp32_fused = util.quiet(model.fuse).eval()
     import copy
     cpu_sd = {k: v.clone() for k, v in fp32_fused.state_dict().items()}
@@ -61,25 +65,46 @@ def build_model(name, device):
     return gpu_model, cpu_sd, float(max(fp32_fused.stride))
 
 
-def cpu_baseline(name, cpu_sd, strides, conf, iou, budget_s=12.0, batch=8):
-    """The CPU oracle (torch-CPU fp32 restatement of the reference + C NMS) on a bounded sample of the same workload."""
+def _cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.lower().startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(name, cpu_sd, strides, conf, iou, budget_s=14.0):
+    """The CPU oracle (torch-CPU fp32 restatement of the reference + C NMS) on a bounded sample of the same workload:
+    a few single images (batch 1, the reference's CPU-runnable case) and batches of 32 (the GPU workload's batch)."""
     import yaml
     from oracle import y5ref, nms_c
     threads = min(16, os.cpu_count() or 1)
     torch.set_num_threads(threads)
     cfg = yaml.safe_load(open(os.path.join(ROOT, 'yolo_amd', 'models', name + '.yaml')))
     g = torch.Generator().manual_seed(1)
-    done, t_total = 0, 0.0
-    with torch.no_grad():
-        while t_total < budget_s and done < 16 * batch:
-            x = torch.rand(batch, 3, 640, 640, generator=g).half().float()
-            t0 = time.time()
-            z, _ = y5ref.forward(cfg, cpu_sd, x, precision='fp32', strides=strides)
-            nms_c.non_max_suppression(z.numpy(), conf, iou)
-            t_total += time.time() - t0
-            done += batch
-    return {'value': round(done / t_total, 2), 'unit': 'images/s', 'cores': threads, 'kind': 'port',
-            'sample': '%d images of the same synthetic 640x640 workload in batches of %d (fp32 torch-CPU forward+decode, C NMS)' % (done, batch)}
+
+    def run(batch, budget, most):
+        done, t_total = 0, 0.0
+        with torch.no_grad():
+            while t_total < budget and done < most:
+                x = torch.rand(batch, 3, 640, 640, generator=g).half().float()
+                t0 = time.time()
+                z, _ = y5ref.forward(cfg, cpu_sd, x, precision='fp32', strides=strides)
+                nms_c.non_max_suppression(z.numpy(), conf, iou)
+                t_total += time.time() - t0
+                done += batch
+        return done, t_total
+
+    run(1, 0.0, 1)  # first call pays thread-pool start-up and lazy initialisation
+    n1, t1 = run(1, budget_s * 0.25, 8)
+    n32, t32 = run(32, budget_s * 0.75, 96)
+    return {'value': round(n32 / t32, 2), 'unit': 'images/s', 'cores': threads, 'kind': 'port', 'cpu': _cpu_model(),
+            'batch1_images_per_s': round(n1 / t1, 2),
+            'sample': '%d images in batches of 32 (value) and %d single images (batch1_images_per_s) of the same synthetic '
+                      '640x640 workload: fp32 torch-CPU forward+decode, C NMS' % (n32, n1)}
 
 
 def main():
@@ -88,32 +113,48 @@ def main():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--model', default='yolov5s')
-    ap.add_argument('--batch', type=int, default=32, help='images per GPU and step')
+    ap.add_argument('--batch', type=int, default=32, help='images per GPU and step (weak scaling)')
+    ap.add_argument('--global-batch', type=int, default=0, help='images per step over all GPUs, sharded (strong scaling)')
     ap.add_argument('--conf', type=float, default=0.001)
     ap.add_argument('--iou', type=float, default=0.65)
+    ap.add_argument('--head-gain', type=float, default=2.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-passes', type=int, default=5)
     args = ap.parse_args()
 
     from yolo_amd import dist as ydist
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: become the supervisor of N rank processes; nothing here has touched a GPU
+        raise SystemExit(ydist.launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
     rank, world, local = ydist.init_from_env()
     if world != args.gpus:
-        raise SystemExit('bench: --gpus %d but WORLD_SIZE is %d (launch N>1 with torch.distributed.run)' % (args.gpus, world))
+        raise SystemExit('bench: --gpus %d but WORLD_SIZE is %d' % (args.gpus, world))
     device = torch.device('cuda', local % max(1, torch.cuda.device_count()))  # ranks share devices only in a rehearsal
     torch.cuda.set_device(device)
     torch.set_grad_enabled(False)
+    if args.global_batch:
+        if args.global_batch % world:
+            raise SystemExit('bench: --global-batch %d is not a multiple of %d GPUs (the gather moves equal blocks)' % (args.global_batch, world))
+        lo, hi = ydist.shard_bounds(args.global_batch, rank, world)
+        args.batch = hi - lo
+        if args.batch <= 0:
+            raise SystemExit('bench: --global-batch %d leaves rank %d without images' % (args.global_batch, rank))
+    global_batch = args.global_batch or args.batch * world
 
     from yolo_amd import engine, nms as hip_nms
     import torch.distributed as dist
-    model, cpu_sd, _ = build_model(args.model, device)
+    model, cpu_sd, _ = build_model(args.model, device, args.head_gain)
     strides = model.stride
     g = torch.Generator().manual_seed(1 + rank)
     x = torch.rand(args.batch, 3, 640, 640, generator=g).half().to(device)
+
+    local_out = [None]
 
     def step():
         z, _ = model(x)
         det, count, kept, ncand = hip_nms.nms_padded(z, args.conf, args.iou, return_index=True, check_overflow=False)
         if world > 1:
+            local_out[0] = (det, count)
             det, count = ydist.gather_detections(det, count)
         return det, count, ncand
 
@@ -125,7 +166,7 @@ def main():
 
     for _ in range(args.warmup):
         out = step()
-    eng = model.__dict__['_y5_engine']
+    eng = engine.engine_of(model)
     if eng.calls < args.warmup:
         raise SystemExit('bench: forward did not run on the HIP engine')
     fence()
@@ -139,6 +180,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     det, count, ncand = out
+    if det.shape[0] != global_batch:
+        raise SystemExit('bench: gathered %d images, expected %d' % (det.shape[0], global_batch))
+    gather_ms = None
+    if world > 1:  # the exchange step on its own: every rank takes part, rank 0 reports
+        reps = 20
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ydist.gather_detections(*local_out[0])
+        fence()
+        t = torch.tensor([(time.perf_counter() - t0) / reps * 1e3], dtype=torch.float64, device='cpu' if dist.get_backend() == 'gloo' else device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        gather_ms = float(t.item())
     cand = ncand.float().mean().item()
     kept = count.float().mean().item()
     if int(ncand.max().item()) > hip_nms.DEFAULT_CANDIDATES:
@@ -147,7 +201,7 @@ def main():
     record = None
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
-        value = args.batch * world * args.steps / elapsed
+        value = global_batch * args.steps / elapsed
         # ---- per-kernel device time from hipEvent pairs around every launch of the plan (same stream)
         acc = None
         for _ in range(args.profile_passes):
@@ -218,10 +272,11 @@ def main():
         record = {
             'metric': 'images/sec at 640x640 fp16 (conv fwd+decode+NMS)', 'value': round(value, 1), 'unit': 'images/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_step, 4),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'strong' if args.global_batch else 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
             'config': {'workload': '%s 640x640 fp16 batch %d per GPU, conf %g iou %g (test.py setting), random-init weights, '
-                                   'BatchNorm-calibrated, head gain 2.0' % (args.model, args.batch, args.conf, args.iou),
-                       'global_batch': args.batch * world, 'parallelism': 'batch shard x%d, detection all_gather' % world,
+                                   'BatchNorm-calibrated, head gain %g' % (args.model, args.batch, args.conf, args.iou, args.head_gain),
+                       'global_batch': global_batch, 'parallelism': 'batch shard x%d, detection all_gather (%s)' % (world, dist.get_backend() if world > 1 else 'none'),
+                       'gather_ms': None if gather_ms is None else round(gather_ms, 4),
                        'candidates_per_image': round(cand, 1), 'kept_per_image': round(kept, 1)},
             'roofline': roofline,
             'stages': {'forward_ms': round(forward_ms, 4), 'plan_ms': round(plan_ms, 4), 'conv_ms': round(conv_ms, 4), 'decode_ms': round(dec_ms, 4), 'decode_kernels': 'head conv + decode fused' if det else 'decode',

@@ -68,3 +68,38 @@ def test_shard_bounds_and_packing():
     cnt = torch.tensor([0, 300, 17], dtype=torch.int32)
     d2, c2 = ydist.unpack_detections(ydist.pack_detections(det, cnt), 300)
     assert torch.equal(d2, det) and torch.equal(c2, cnt)
+
+
+_RANK_SCRIPT = '''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from yolo_amd import dist as ydist
+rank, world, local = ydist.init_from_env(backend='gloo')
+t = torch.tensor([float(rank + 1)])
+dist.all_reduce(t)
+open(os.path.join(%r, 'rank%%d.txt' %% rank), 'w').write('%%d %%d %%g' %% (world, local, t.item()))
+print('hello from rank %%d' %% rank)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_launch_ranks_starts_one_process_per_rank(tmp_path):
+    """The launcher behind a plain `python bench.py --gpus N`: rank processes get the torch.distributed.run environment,
+    rendezvous on 127.0.0.1 and all exit 0."""
+    import sys
+    script = tmp_path / 'rank.py'
+    script.write_text(_RANK_SCRIPT % (util.ROOT, str(tmp_path)))
+    rc = ydist.launch_ranks([sys.executable, str(script)], 2, timeout=120)
+    assert rc == 0
+    assert (tmp_path / 'rank0.txt').read_text() == '2 0 3' and (tmp_path / 'rank1.txt').read_text() == '2 1 3'
+
+
+def test_launch_ranks_reports_a_failing_rank_and_stops_the_rest(tmp_path):
+    import sys
+    script = tmp_path / 'fail.py'
+    script.write_text('import os, sys, time\nif os.environ["RANK"] == "1":\n    sys.exit(3)\ntime.sleep(60)\n')
+    import time
+    t0 = time.time()
+    assert ydist.launch_ranks([sys.executable, str(script)], 2, timeout=120) == 3
+    assert time.time() - t0 < 30

@@ -15,8 +15,7 @@ pytestmark = pytest.mark.gpu
 
 
 def calls(model):
-    eng = model.__dict__.get('_y5_engine')
-    return eng.calls if eng else 0
+    return engine.calls(model)
 
 
 # The bar is the tolerance.  The bit-identical fraction is a sanity floor only, set well below what is measured

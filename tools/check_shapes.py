@@ -19,7 +19,7 @@ for cfg, pruned in (('yolov5s', False), ('yolov5s_ori', True), ('yolov5m', False
     for B, H, W in ((1, 320, 256), (3, 416, 416), (2, 608, 352), (5, 224, 640), (1, 64, 64), (7, 160, 96)):
         x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(B * H + W)).half().to(dev)
         z, xs = model(x)
-        eng = model.__dict__['_y5_engine']
+        eng = engine.engine_of(model)
         with engine.disabled():
             zt, xt = model(x)
         d = (z.float() - zt.float()).abs()

@@ -104,7 +104,7 @@ for cfg in ('yolov5s', 'yolov5s_ori'):
     sdh = {k: v.float().cpu() for k, v in mh.state_dict().items()}
     (zr, xr), feats = y5ref.forward(cfgd, sdh, x.half().float(), precision='half', strides=model.stride, return_features=True)
     zg, xg = mh(x.half().to(dev))
-    print(cfg, 'engine calls', mh._y5_engine.calls if hasattr(mh, '_y5_engine') else mh.__dict__.get('_y5_engine').calls)
+    print(cfg, 'engine calls', __import__('yolo_amd.engine', fromlist=['x']).calls(mh))
     for i in range(3):
         stats('%s x%d' % (cfg, i), xg[i], xr[i])
     stats(cfg + ' z', zg, zr)

@@ -23,7 +23,8 @@ m = m.eval().half().to(dev)
 x = torch.rand(a.batch, 3, a.size, a.size, generator=torch.Generator().manual_seed(1)).half().to(dev)
 for _ in range(3):
     z, _ = m(x)
-eng = m.__dict__['_y5_engine']
+from yolo_amd import engine as _eng_mod
+eng = _eng_mod.engine_of(m)
 acc = None
 for _ in range(a.passes):
     rows = eng.profile(x)

@@ -410,8 +410,27 @@ def adaptive_bn(in_model, dataloader, deepcp=True, device=None):
     model.train()
     rec = Recalibrator(model)
     device = device or rec.device
+    done = 0
     with torch.no_grad():
-        for batch in dataloader:
+        it = iter(dataloader)
+        for batch in it:
             inputs = batch[0] if isinstance(batch, (tuple, list)) else batch
-            rec.step(inputs.to(device, non_blocking=True))
+            inputs = inputs.to(device, non_blocking=True)
+            if inputs.dtype is not torch.uint8:
+                # the reference divides every batch by 255 whatever its dtype (fp_train.py:239); Recalibrator.step only
+                # does so for uint8 and takes a float batch as already normalised
+                inputs = inputs.float() / 255.0
+            try:
+                rec.step(inputs)
+            except Unsupported:
+                if done:
+                    raise  # statistics already moved by the kernels: cannot hand the same batches to torch again
+                # a model the kernels do not take (grouped or biased convolutions, fused Conv modules ...): the reference's
+                # own loop on the torch modules, this batch included
+                import itertools
+                for b in itertools.chain([batch], it):
+                    x = b[0] if isinstance(b, (tuple, list)) else b
+                    model(x.to(device, non_blocking=True).float() / 255.0)
+                return model
+            done += 1
     return rec.finish()

@@ -70,7 +70,7 @@ __device__ __forceinline__ void decode_from_lds(const DecodeArgs& a, int b, int 
         const f16* col = tile + an * a.no;
         if (VEC) {
             // A window of 8 consecutive outputs lies in pixel p from slot o on and, past that pixel's last slot, in pixel
-            // p + 1 from slot 0 on (no >= 8).  Every element gets the sigmoid; the few windows that touch a pixel's four
+            // p + 1 from slot 0 on (prepare_level allows this path from no = 6 on).  Every element gets the sigmoid; the few windows that touch a pixel's four
             // box slots are patched from the pre-decoded array afterwards.
             const int skip = a.lds_ld - a.no;
             for (int e0 = threadIdx.x * 8; e0 < run; e0 += kThreads * 8) {
@@ -161,7 +161,9 @@ inline int prepare_level(const y5_decode_desc& d, DecodeArgs& a, size_t* lds_byt
 
     // 16-byte stores need every per-anchor run to start on a multiple of 8 elements in both tensors:
     // runs start at ((b*na + an)*npix + pix0)*no and (b*rows + row0 + an*npix + pix0)*no with pix0 % 64 == 0.
-    *vec = (((long long)npix * d.no) % 8 == 0) && (((long long)d.z_rows_total * d.no) % 8 == 0) &&
+    // and the 8-wide windows assume that a window touches at most pixels p and p + 1, which holds from 6 outputs per
+    // anchor on (6: window starts are even; 7: a window ends in slot 6 of p + 1 at the latest).
+    *vec = d.no >= 6 && (((long long)npix * d.no) % 8 == 0) && (((long long)d.z_rows_total * d.no) % 8 == 0) &&
            (((long long)d.z_row0 * d.no) % 8 == 0) && y5_aligned16(d.z_out) && y5_aligned16(d.x_out);
     return Y5_OK;
 }

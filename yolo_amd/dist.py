@@ -7,6 +7,10 @@ over RCCL (backend "nccl" on ROCm) - or gloo on the CPU in tests.  The reference
 its evaluation is single-GPU (test.py:74-76).
 """
 import os
+import socket
+import subprocess
+import sys
+import time
 
 import torch
 import torch.distributed as dist
@@ -72,3 +76,52 @@ def to_list(det, count):
     """Padded detections -> the reference's list[None | Tensor(n, 6)] (utils/utils.py:584,641)."""
     counts = count.tolist()
     return [det[b, :c].clone() if c > 0 else None for b, c in enumerate(counts)]
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(argv, world, env=None, timeout=None):
+    """Start `world` child processes running `argv` (a full command line, e.g. [sys.executable, 'bench.py', ...]), one
+    per rank, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set the way torch.distributed.run sets
+    them, and wait for them.  Meant to be called BEFORE the calling process has touched a GPU: the parent only
+    supervises.  Rank 0 inherits stdout (its one JSON line is the job's output), the other ranks' stdout is dropped,
+    stderr is inherited by all.  When there are fewer GPUs than ranks the children are told to rehearse on the gloo
+    backend (Y5_DIST_BACKEND) and share devices.  Returns 0 when every rank exited 0, else the first non-zero exit
+    code; on a failure or a timeout the remaining children are terminated (by their own PIDs)."""
+    base = dict(os.environ if env is None else env)
+    base.setdefault('MASTER_ADDR', '127.0.0.1')
+    base['MASTER_PORT'] = str(free_port())
+    base['WORLD_SIZE'] = str(world)
+    if 'Y5_DIST_BACKEND' not in base and torch.cuda.device_count() < world:  # device_count() does not initialise the GPU
+        base['Y5_DIST_BACKEND'] = 'gloo'
+    procs = []
+    for rank in range(world):
+        e = dict(base, RANK=str(rank), LOCAL_RANK=str(rank))
+        out = None if rank == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen(list(argv), env=e, stdout=out))
+    deadline = None if timeout is None else time.time() + timeout
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+        if rc != 0 or (deadline is not None and time.time() > deadline):
+            for p in live:
+                p.terminate()
+            for p in live:
+                try:
+                    p.wait(10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            return rc or 124
+        time.sleep(0.05)
+    return rc

@@ -13,9 +13,12 @@ A concatenation is a wider buffer whose producers write their channel slice dire
 Shapes and parameters are read from the live modules (weight.shape, not the yaml), which is what
 makes pruned models work, and the plan is rebuilt whenever parameters change identity or version.
 """
+import collections
 import ctypes as C
+import json
 import math
 import os
+import weakref
 
 import torch
 import torch.nn as nn
@@ -26,6 +29,51 @@ from yolo_amd.utils.torch_utils import bn_affine
 _DISABLED = [0]
 _TUNED = {}   # conv shape key -> fastest variant id, shared by all plans of the process
 _TUNED_MS = {}  # key -> milliseconds per launch of the chosen variant
+_ENGINES = weakref.WeakKeyDictionary()  # model -> Engine; kept out of the module so that deepcopy / pickle / torch.save of
+#                                         a model that has run on the engine see no ctypes handles
+MAX_PLANS = int(os.environ.get('Y5_MAX_PLANS', '4'))  # launch plans (one per input shape) an Engine keeps; least recently used goes first
+
+
+def _cache_key(key):
+    return json.dumps(key)
+
+
+def load_tune_cache(path):
+    """Read variant choices written by save_tune_cache: later plans of those shapes take them without timing anything."""
+    with open(path) as f:
+        data = json.load(f)
+    for k, (variant, ms) in data.items():
+        key = tuple(json.loads(k))
+        _TUNED[key], _TUNED_MS[key] = int(variant), float(ms)
+    return len(data)
+
+
+def save_tune_cache(path):
+    """Write every variant choice of this process (shape key -> [variant, ms]) as JSON."""
+    data = {_cache_key(list(k)): [v, _TUNED_MS.get(k, 0.0)] for k, v in _TUNED.items()}
+    tmp = '%s.%d.tmp' % (path, os.getpid())
+    with open(tmp, 'w') as f:
+        json.dump(data, f, indent=0, sort_keys=True)
+    os.replace(tmp, path)
+    return len(data)
+
+
+def _tune_cache_init():
+    """Y5_TUNE_CACHE=<file>: choices are read from it at import (when it exists) and written back at exit, so that a
+    second process - a profiler run, a test that wants the same kernels twice - replays the first one's plan."""
+    path = os.environ.get('Y5_TUNE_CACHE')
+    if not path:
+        return
+    if os.path.exists(path):
+        try:
+            load_tune_cache(path)
+        except (ValueError, OSError):
+            pass
+    import atexit
+    atexit.register(lambda: _TUNED and save_tune_cache(path))
+
+
+_tune_cache_init()
 
 
 class disabled:
@@ -91,11 +139,22 @@ def run(model, x):
 
 
 def _engine_of(model):
-    eng = model.__dict__.get('_y5_engine')
+    eng = _ENGINES.get(model)
     if eng is None:
         eng = Engine(model)
-        model.__dict__['_y5_engine'] = eng  # plain attribute: not a sub-module, not pickled state we rely on
+        _ENGINES[model] = eng
     return eng
+
+
+def engine_of(model):
+    """The Engine that has served `model` so far, or None (tests and benchmarks read its counters)."""
+    return _ENGINES.get(model)
+
+
+def calls(model):
+    """Number of forwards of `model` that ran as HIP kernels."""
+    eng = _ENGINES.get(model)
+    return eng.calls if eng is not None else 0
 
 
 # --------------------------------------------------------------------------------------------
@@ -850,7 +909,10 @@ class Plan:
         if self.lib.y5_detect_f16(C.byref(cd), C.byref(dd), 0, stream) != 0:
             return None
         best, best_t = 0, float('inf')
-        if os.environ.get('Y5_AUTOTUNE', '1') != '0':
+        key = ('detect', cd.batch, cd.h, cd.w_in, cd.cin, cd.x_ld, cd.cout, dd.na, dd.no)
+        if key in _TUNED:
+            best = _TUNED[key]
+        elif os.environ.get('Y5_AUTOTUNE', '1') != '0':
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             for v in range(1, self.lib.y5_detect_num_variants() + 1):
                 if self.lib.y5_detect_f16(C.byref(cd), C.byref(dd), v, stream) != 0:
@@ -862,6 +924,7 @@ class Plan:
                 e1.synchronize()
                 if e0.elapsed_time(e1) < best_t:
                     best, best_t = v, e0.elapsed_time(e1)
+            _TUNED[key], _TUNED_MS[key] = best, best_t / 4
         label = 'detect.m%d conv1x1+decode %d->%d @%dx%d v%d' % (lvl, f.c_log, cout, f.h, f.w, best)
         return label, cd, dd, best
 
@@ -976,11 +1039,15 @@ class Engine:
     """Per-model cache of launch plans keyed by input shape and by the identity/version of every parameter."""
 
     def __init__(self, model):
-        self.model = model
-        self.plans = {}
+        self._model = weakref.ref(model)  # the registry maps model -> Engine weakly; a strong reference here would pin both
+        self.plans = collections.OrderedDict()
         self.signature = None
         self.unsupported = None   # (signature, reason) of the last failed lowering
         self.calls = 0            # forwards executed by HIP kernels (read by tests)
+
+    @property
+    def model(self):
+        return self._model()
 
     def _signature(self):
         sig = []
@@ -1009,6 +1076,12 @@ class Engine:
                 self.unsupported = ((sig, key), str(e))
                 return None
             self.plans[key] = plan
+            while len(self.plans) > max(1, MAX_PLANS):  # a rectangular-batch loader feeds many shapes: bound the buffers held
+                _, old = self.plans.popitem(last=False)
+                torch.cuda.synchronize(x.device)  # launches of the evicted plan may still be in flight on any stream
+                old.close()
+        else:
+            self.plans.move_to_end(key)
         return plan
 
     def supported(self, x):

@@ -57,7 +57,8 @@ def compute_ap(recall, precision):
     pre = np.concatenate(([0.0], precision, [0.0]))
     pre = np.maximum.accumulate(pre[::-1])[::-1]        # monotone envelope from the right
     grid = np.linspace(0, 1, 101)
-    return np.trapezoid(np.interp(grid, rec, pre), grid)
+    trapz = getattr(np, 'trapezoid', None) or np.trapz  # numpy < 2.0 only has trapz
+    return trapz(np.interp(grid, rec, pre), grid)
 
 
 def ap_per_class(tp, conf, pred_cls, target_cls, pr_score=0.1):
