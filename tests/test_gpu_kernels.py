@@ -437,3 +437,66 @@ def test_detect_level_in_one_kernel_equals_conv_then_decode(dev, shape):
             assert bool((d <= 2e-3 * ref.float().abs() + 2e-3 * ref.float().abs().max()).all()), float(d.max())
         assert float((x_got == x_ref).float().mean()) > 0.97
     assert taken == (0 if (ny * nx * no) % 8 else lib.y5_detect_num_variants() + 1)
+
+
+@pytest.mark.parametrize('nc', [1, 2, 3])
+def test_decode_small_class_counts_on_aligned_levels(dev, nc):
+    """nc = 1 / 2 (6 / 7 outputs per anchor) on levels whose runs are 16-byte aligned, so that the vector store path
+    runs (the reference fixture for nc = 1 has odd sizes and takes the scalar path): one launch per level and all levels
+    in one launch against the oracle's half-mode decode, and the one-kernel Detect level against the two-kernel path."""
+    lib = _lib.lib()
+    no, na, B = nc + 5, 3, 2
+    g = torch.Generator().manual_seed(nc)
+    sizes, strides = [(16, 16), (8, 8), (4, 4)], [8., 16., 32.]
+    raws = [(torch.randn(B, na * no, ny, nx, generator=g) * 3).half() for ny, nx in sizes]
+    ag = torch.tensor([[10., 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]).view(3, 1, 3, 1, 1, 2)
+    zr, xr = y5ref.detect_decode(raws, ag, torch.tensor(strides), True)
+    assert (zr.shape[1] * no) % 8 == 0
+    zo = torch.zeros(zr.shape, dtype=torch.float16, device=dev)
+    row0 = 0
+    for i, raw in enumerate(raws):
+        xo = decode_level(dev, raw.to(dev), strides[i], ag[i].view(3, 2), zo, row0, no)
+        assert torch.equal(xo.cpu(), xr[i])
+        row0 += na * raw.shape[2] * raw.shape[3]
+    assert torch.equal(zo.cpu().view(torch.int16), zr.view(torch.int16))
+    # all levels in one launch
+    zo2 = torch.zeros_like(zo)
+    levels = (_lib.DecodeDesc * 3)()
+    keep, row0 = [], 0
+    for i, raw in enumerate(raws):
+        ld = (na * no + 7) // 8 * 8
+        head = nhwc(raw.to(dev), ld, dev)
+        xo = torch.zeros(B, na, raw.shape[2], raw.shape[3], no, dtype=torch.float16, device=dev)
+        keep += [head, xo]
+        d = levels[i]
+        d.head, d.head_ld, d.x_out, d.z_out = head.data_ptr(), ld, xo.data_ptr(), zo2.data_ptr()
+        d.batch, d.ny, d.nx, d.na, d.no = B, raw.shape[2], raw.shape[3], na, no
+        d.z_rows_total, d.z_row0, d.stride = zr.shape[1], row0, strides[i]
+        for a in range(na):
+            d.anchor_wh[2 * a], d.anchor_wh[2 * a + 1] = float(ag[i, 0, a, 0, 0, 0]), float(ag[i, 0, a, 0, 0, 1])
+        row0 += na * raw.shape[2] * raw.shape[3]
+    _lib.check(lib.y5_detect_decode_multi_f16(levels, 3, _lib.current_stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(zo2, zo)
+
+
+@pytest.mark.parametrize('nc', [1, 2])
+def test_small_class_count_model_runs_on_the_engine(dev, nc):
+    """A whole nc = 1 / 2 graph at a size whose levels are aligned (Detect levels as one kernel each): against the oracle."""
+    import os
+    import yaml
+    from yolo_amd import engine
+    model = util.build_model('yolov5s', nc=nc)
+    util.randomize_bn(model, 11)
+    model = model.eval().half().to(dev)
+    x = torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(5)).half()
+    z, xs = model(x.to(dev))
+    assert engine.calls(model) == 1 and z.shape == (2, 3 * (256 + 64 + 16), nc + 5)
+    cfgd = yaml.safe_load(open(os.path.join(util.CFG_DIR, 'yolov5s.yaml')))
+    cfgd['nc'] = nc
+    sd = {k: v.float().cpu() for k, v in model.state_dict().items()}
+    zr, xr = y5ref.forward(cfgd, sd, x.float(), precision='half', strides=model.stride)
+    for got, ref in list(zip(xs, xr)) + [(z, zr)]:
+        d = (got.float().cpu() - ref.float()).abs()
+        assert bool((d <= 4e-3 * ref.float().abs() + 4e-3 * ref.float().abs().max()).all()), float(d.max())
+    assert float((z.cpu() == zr).float().mean()) > 0.9

@@ -143,3 +143,30 @@ def test_adaptive_bn_has_no_cpu_path():
         Recalibrator(model)
     with pytest.raises(RuntimeError):
         adaptive_bn(model, [torch.zeros(1, 3, 64, 64, dtype=torch.uint8)])
+
+
+def test_checkpoint_with_the_reference_module_paths_loads_through_attempt_load(tmp_path):
+    """models/experimental.py:128-141 on the CPU: a whole-module checkpoint whose pickle names models.yolo.Model /
+    models.common.* (what the reference's training scripts write) resolves to the mirror classes, comes back fp32, fused
+    and in eval mode, and computes what the directly fused model computes; two files give the mean Ensemble."""
+    import copy
+    from test_gpu_boundary import _save_like_the_reference
+    from yolo_amd.models.experimental import Ensemble, attempt_load
+    paths, direct = [], []
+    for seed in (0, 1):
+        m = util.build_model('yolov5s', seed=seed)
+        util.randomize_bn(m, 11 + seed)
+        m.names = ['c%d' % i for i in range(80)]
+        p = str(tmp_path / ('m%d.pt' % seed))
+        _save_like_the_reference(m.half(), p)   # strip_optimizer stores half checkpoints (utils/utils.py:648-654)
+        paths.append(p)
+        direct.append(util.quiet(copy.deepcopy(m).float().fuse).eval())
+    x = torch.rand(1, 3, 64, 96, generator=torch.Generator().manual_seed(8))
+    with torch.no_grad():
+        one = util.quiet(attempt_load, paths[0], map_location='cpu')
+        assert type(one).__name__ == 'Model' and not one.training and next(one.parameters()).dtype is torch.float32
+        assert torch.equal(one(x)[0], direct[0](x)[0])
+        ens = util.quiet(attempt_load, paths, map_location='cpu')
+        assert isinstance(ens, Ensemble) and len(ens) == 2 and ens.names == one.names
+        y, none = ens(x)
+        assert none is None and torch.equal(y, torch.stack([direct[0](x)[0], direct[1](x)[0]]).mean(0))

@@ -719,7 +719,7 @@ int y5_launch_detect(const y5_conv_desc& c, const y5_decode_desc& d, int variant
     size_t lds_bytes = 0;
     bool vec = false;
     if (int rc = prepare_level(d, dec, &lds_bytes, &vec)) return rc;
-    Y5_REQUIRE(vec, "detect: the fused kernel needs 16-byte aligned output runs (ny*nx*no, rows*no, row0*no multiples of 8)");
+    Y5_REQUIRE(vec, "detect: the fused kernel needs 16-byte aligned output runs (ny*nx*no, rows*no, row0*no multiples of 8, no >= 6)");
     const long long xb = (((long long)c.batch * c.h * c.w_in - 1) * c.x_ld + c.cin) * 2, wb = (long long)c.w_rows * c.kpad * 2;
     Y5_REQUIRE(xb < 0x7fffffffLL && wb < 0x7fffffffLL, "detect: tensors of 2 GiB or more");
     ConvArgs a{};
