@@ -285,6 +285,16 @@ typedef struct y5_nms_desc {
 size_t y5_nms_workspace_bytes(int batch, int max_candidates);
 int y5_nms_batched(const y5_nms_desc* d, y5_stream_t stream);
 
+/* y5_nms_batched for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same descriptor, same results bit for bit;
+ * d->workspace and d->workspace_bytes are ignored: counters and sort keys live in a device array inside the library,
+ * Y5_NMS_NOALLOC_BYTES per GPU the library runs on, held until the process ends.  The call allocates and frees
+ * nothing.  y5_nms_workspace_bytes(batch, max_candidates) must not exceed Y5_NMS_NOALLOC_BYTES (batch 32 with 65536
+ * candidates per image just fits), else Y5_EWORKSPACE.  All calls on one GPU share the array: calls
+ * that overlap in time on one GPU (different streams or threads) race; calls on one stream are ordered and safe. */
+#define Y5_NMS_NOALLOC_BYTES ((size_t)(16u << 20) + 4096u) /* 2 Mi sort keys (batch * pow2(max_candidates)) + counters of up to 1024 images */
+int y5_nms_batched_noalloc(const y5_nms_desc* d, y5_stream_t stream);
+
 /* Prediction <-> label matching of the evaluation loop, for a whole batch, without a host round trip.
  * Replaces: test.py:199 (clip_coords(pred, (height, width)), done in place on det) and test.py:220-247 (per class:
  * box_iou(pred, tbox).max(1), predictions in confidence order claim their best label once, correct = iou > iouv).

@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, 'liby5hip.so')
 
 Y5_MAX_ANCHORS = 8
 Y5_MAX_LEVELS = 4
+NMS_NOALLOC_BYTES = (16 << 20) + 4096  # Y5_NMS_NOALLOC_BYTES
 PLAN_SIDE, PLAN_JOIN = 1, 2
 ACT_NONE, ACT_LEAKY = 0, 1
 OK, EINVAL, EHIP, ENOMEM, EWORKSPACE = 0, -1, -2, -3, -4  # y5_status in include/y5hip.h
@@ -77,6 +78,7 @@ SIGNATURES = {
     'y5_sigmoid_f16': (_i, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, _s]),
     'y5_nms_workspace_bytes': (C.c_size_t, [_i, _i]),
     'y5_nms_batched': (_i, [C.POINTER(NmsDesc), _s]),
+    'y5_nms_batched_noalloc': (_i, [C.POINTER(NmsDesc), _s]),
     'y5_match_predictions_f32': (_i, [C.c_void_p, C.c_void_p, C.c_void_p, _i, C.c_void_p, _i, C.c_void_p, C.c_void_p, _i, _i, _i,
                                       C.c_float, C.c_float, _s]),
     'y5_scale_coords_f32': (_i, [C.c_void_p, C.c_void_p, C.c_void_p, _i, _i, _i, _i, _s]),

@@ -649,22 +649,26 @@ extern "C" size_t y5_nms_workspace_bytes(int batch, int max_candidates) {
     return counters + (size_t)batch * pow2_at_least(max_candidates) * sizeof(u64);
 }
 
-extern "C" int y5_nms_batched(const y5_nms_desc* d, y5_stream_t stream) {
+namespace {
+
+// Argument checks shared by the two batched entry points (everything but the workspace).
+int nms_check(const y5_nms_desc* d) {
     Y5_REQUIRE(d, "nms: null descriptor");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    Y5_REQUIRE(d->pred && d->workspace && d->det && d->count, "nms: null pointer");
+    Y5_REQUIRE(d->pred && d->det && d->count, "nms: null pointer");
     Y5_REQUIRE(d->pred_dtype == 0 || d->pred_dtype == 1, "nms: pred_dtype %d not in {0 fp16, 1 fp32}", d->pred_dtype);
     Y5_REQUIRE(d->batch > 0 && d->n_rows > 0 && d->no >= 6, "nms: bad shape (%d, %d, %d)", d->batch, d->n_rows, d->no);
     Y5_REQUIRE((long long)d->n_rows * (d->no - 5) < 0x7fffffffLL, "nms: rows*classes overflows the 32-bit candidate index");
     Y5_REQUIRE(d->max_det > 0 && d->max_det <= MAX_DET_CAP, "nms: max_det %d out of range 1..%d", d->max_det, MAX_DET_CAP);
     Y5_REQUIRE(d->max_candidates > 0, "nms: max_candidates must be positive");
     Y5_REQUIRE(d->conf_thres >= 0.f, "nms: conf_thres must be >= 0");
-    const size_t need = y5_nms_workspace_bytes(d->batch, d->max_candidates);
-    if (d->workspace_bytes < need) return y5_fail(Y5_EWORKSPACE, "nms: workspace %zu < %zu bytes", d->workspace_bytes, need);
-    Y5_REQUIRE(y5_aligned16(d->workspace), "nms: workspace must be 16-byte aligned");
+    return Y5_OK;
+}
+
+// The three stages on `workspace` (y5_nms_workspace_bytes(batch, max_candidates) bytes, 16-byte aligned): counters, then keys.
+int nms_run(const y5_nms_desc* d, void* workspace, hipStream_t s) {
     const size_t counters_bytes = ((size_t)d->batch * sizeof(int) + 255) / 256 * 256;
-    int* counters = static_cast<int*>(d->workspace);
-    u64* keys = reinterpret_cast<u64*>(static_cast<unsigned char*>(d->workspace) + counters_bytes);
+    int* counters = static_cast<int*>(workspace);
+    u64* keys = reinterpret_cast<u64*>(static_cast<unsigned char*>(workspace) + counters_bytes);
     const int cap_pow2 = pow2_at_least(d->max_candidates);
 
     Y5_HIP(hipMemsetAsync(counters, 0, counters_bytes, s));
@@ -701,6 +705,46 @@ extern "C" int y5_nms_batched(const y5_nms_desc* d, y5_stream_t stream) {
     hipLaunchKernelGGL(nms_clear_tail_kernel, dim3((unsigned)d->batch), dim3(256), 0, s, d->det, d->kept_index, d->count, d->max_det);
     Y5_LAUNCH_CHECK("nms_clear_tail_kernel");
     return Y5_OK;
+}
+
+}  // namespace
+
+extern "C" int y5_nms_batched(const y5_nms_desc* d, y5_stream_t stream) {
+    if (int rc = nms_check(d)) return rc;
+    Y5_REQUIRE(d->workspace, "nms: null pointer");
+    const size_t need = y5_nms_workspace_bytes(d->batch, d->max_candidates);
+    if (d->workspace_bytes < need) return y5_fail(Y5_EWORKSPACE, "nms: workspace %zu < %zu bytes", d->workspace_bytes, need);
+    Y5_REQUIRE(y5_aligned16(d->workspace), "nms: workspace must be 16-byte aligned");
+    return nms_run(d, d->workspace, static_cast<hipStream_t>(stream));
+}
+
+// ------------------------------------------------------------------------------------------
+// The same pipeline for callers that cannot allocate: counters and sort keys live in a device array of this code object.
+// ------------------------------------------------------------------------------------------
+static __device__ __align__(256) unsigned char scratch[Y5_NMS_NOALLOC_BYTES];
+
+namespace {
+constexpr int NOALLOC_MAX_DEVICES = 64;
+std::atomic<void*> scratch_ptr[NOALLOC_MAX_DEVICES];  // device address of `scratch` on each device, resolved on first use there
+}  // namespace
+
+extern "C" int y5_nms_batched_noalloc(const y5_nms_desc* d, y5_stream_t stream) {
+    if (int rc = nms_check(d)) return rc;
+    const size_t need = y5_nms_workspace_bytes(d->batch, d->max_candidates);
+    if (need > (size_t)Y5_NMS_NOALLOC_BYTES)
+        return y5_fail(Y5_EWORKSPACE, "nms_noalloc: batch %d x %d candidates needs %zu bytes of scratch, the built-in array holds %zu; "
+                       "lower max_candidates or use y5_nms_batched with a workspace", d->batch, d->max_candidates, need, (size_t)Y5_NMS_NOALLOC_BYTES);
+    int dev = 0;
+    Y5_HIP(hipGetDevice(&dev));
+    Y5_REQUIRE(dev >= 0 && dev < NOALLOC_MAX_DEVICES, "nms_noalloc: device ordinal %d out of range", dev);
+    void* ws = scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!ws) {
+        // every device holds its own copy of the array at its own address; the array's name is only a host-side handle
+        Y5_HIP(hipGetSymbolAddress(&ws, HIP_SYMBOL(scratch)));
+        Y5_REQUIRE(ws && y5_aligned16(ws), "nms_noalloc: bad scratch address");
+        scratch_ptr[dev].store(ws, std::memory_order_release);
+    }
+    return nms_run(d, ws, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int y5_scale_coords_f32(float* det, const int32_t* count, const float* params, int batch, int max_det, int row_floats,
