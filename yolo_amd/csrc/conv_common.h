@@ -55,6 +55,11 @@ struct ConvArgs {
     // sum of squares, r = M-tile index % stats_rows, channel n at column stats_off + n; nullptr = off
     float* stats;
     int stats_rows, stats_c, stats_off;
+    // linear-halo 3x3 kernel (conv_lin3.hip): bytes per staged pixel (channels + one 16-byte slot of padding), staged
+    // pixels, 1 KiB DMA pieces of the halo, input pixels of the whole batch
+    int lin_pitch, lin_hpx, lin_pieces;
+    long long lin_min;
+    FastDiv div_slots;
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -108,6 +113,24 @@ __device__ __forceinline__ void dma16_buf(i32x4 rsrc, unsigned voff, unsigned ld
         : "v"(voff), "s"(rsrc), "s"(lds_base)
         : "memory");
 }
+
+// buffer_load_dwordx4 ... lds: the wave writes 1 KiB at the wave-uniform LDS address dst, lane i at dst + 16*i, from
+// descriptor base + voff (per lane) + soff (wave-uniform); a lane whose offset fails the descriptor's range check gets
+// zeros.  The descriptor type and builtins exist in the device pass only.
+typedef __attribute__((address_space(3))) unsigned char* lds_ptr;
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+__device__ __forceinline__ BufRsrc make_rsrc(const void* p, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ void buf_dma16(BufRsrc r, lds_ptr dst, unsigned voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, voff, soff, 0, 0);
+}
+#else
+struct BufRsrc {};
+__device__ inline BufRsrc make_rsrc(const void*, int) { return BufRsrc{}; }
+__device__ inline void buf_dma16(BufRsrc, lds_ptr, unsigned, int) {}
+#endif
 
 // Wait until at most n of this wave's vector-memory operations are outstanding, then meet the workgroup.
 __device__ __forceinline__ void wait_vm_and_barrier(int n) {

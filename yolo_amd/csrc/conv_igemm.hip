@@ -459,7 +459,8 @@ const Cat2Variant kCat2[] = {
 constexpr int kNumCat2 = (int)(sizeof(kCat2) / sizeof(kCat2[0]));
 
 // Every compiled tile configuration. Index + 1 is the public variant id (0 = choose by rule); ids past the end
-// of this table select the other kernel families in turn (conv_halo.hip, conv_ws1x1.hip, conv3x3_ws.hip, conv_lw.hip).
+// of this table select the other kernel families in turn (conv_halo.hip, conv_ws1x1.hip, conv3x3_ws.hip, conv_lw.hip,
+// conv_lin3.hip).
 struct Variant {
     int bm, bn, bk, s;
     int (*launch)(const ConvArgs&, int, bool, hipStream_t);
@@ -517,12 +518,16 @@ int y5_launch_conv(const y5_conv_desc& d, hipStream_t s, const Y5ConvStats* st) 
     Y5_REQUIRE(d.act == Y5_ACT_NONE || d.act == Y5_ACT_LEAKY, "conv: unknown activation %d", d.act);
     Y5_REQUIRE(d.act == Y5_ACT_NONE || (d.slope > 0.f && d.slope <= 1.f), "conv: LeakyReLU slope %g outside (0, 1]", (double)d.slope);
 
-    Y5_REQUIRE(d.variant >= 0 && d.variant <= kNumIgemm + kNumHalo + kNumWs + kNumWs3 + y5_conv_lw_count(), "conv: variant %d out of range 0..%d",
-               d.variant, kNumIgemm + kNumHalo + kNumWs + kNumWs3 + y5_conv_lw_count());
+    Y5_REQUIRE(d.variant >= 0 && d.variant <= y5_conv_variant_count(), "conv: variant %d out of range 0..%d", d.variant, y5_conv_variant_count());
     if (st) {
         Y5_REQUIRE(st->partials && st->rows > 0 && st->c > 0 && st->off >= 0 && st->off + d.cout <= st->c, "conv: statistics columns %d..+%d outside 0..%d (rows %d)", st->off, d.cout, st->c, st->rows);
         Y5_REQUIRE((reinterpret_cast<uintptr_t>(st->partials) & 3) == 0, "conv: misaligned statistics pointer");
         if (d.variant > kNumIgemm) return y5_fail(Y5_EINVAL, "conv: variant %d does not accumulate statistics (variants 1..%d do)", d.variant, kNumIgemm);
+    }
+    if (d.variant > kNumIgemm + kNumHalo + kNumWs + kNumWs3 + y5_conv_lw_count()) {
+        int rc = Y5_OK;
+        if (y5_try_conv_lin(d, s, d.variant - kNumIgemm - kNumHalo - kNumWs - kNumWs3 - y5_conv_lw_count(), &rc)) return rc;
+        return y5_fail(Y5_EINVAL, "conv: the linear-halo variant %d does not apply to this shape", d.variant);
     }
     if (d.variant > kNumIgemm + kNumHalo + kNumWs + kNumWs3) {
         int rc = Y5_OK;
@@ -617,7 +622,7 @@ int y5_launch_conv(const y5_conv_desc& d, hipStream_t s, const Y5ConvStats* st) 
     return kVariants[v].launch(a, d.ksize, direct, s);
 }
 
-int y5_conv_variant_count() { return kNumIgemm + kNumHalo + kNumWs + kNumWs3 + y5_conv_lw_count(); }
+int y5_conv_variant_count() { return kNumIgemm + kNumHalo + kNumWs + kNumWs3 + y5_conv_lw_count() + y5_conv_lin_count(); }
 
 int y5_conv_cat2_variant_count() { return kNumCat2; }
 

@@ -15,24 +15,6 @@ namespace {
 #include "conv_common.h"
 #include "decode_tile.h"
 
-// buffer_load_dwordx4 ... lds: the wave writes 1 KiB at the wave-uniform LDS address dst, lane i at dst + 16*i, from
-// descriptor base + voff (per lane) + soff (wave-uniform); a lane whose offset fails the descriptor's range check gets
-// zeros.  The descriptor type and builtins exist in the device pass only.
-typedef __attribute__((address_space(3))) unsigned char* lds_ptr;
-#if defined(__HIP_DEVICE_COMPILE__)
-typedef __amdgpu_buffer_rsrc_t BufRsrc;
-__device__ __forceinline__ BufRsrc make_rsrc(const void* p, int bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ void buf_dma16(BufRsrc r, lds_ptr dst, unsigned voff, int soff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, voff, soff, 0, 0);
-}
-#else
-struct BufRsrc {};
-__device__ inline BufRsrc make_rsrc(const void*, int) { return BufRsrc{}; }
-__device__ inline void buf_dma16(BufRsrc, lds_ptr, unsigned, int) {}
-#endif
-
 template <int BM, int BN, int WM, int WN, int NL, int S, int BK>
 struct LwCfg {
     static constexpr int NT = 64 * (WM * WN + NL);
