@@ -45,7 +45,11 @@ __device__ unsigned long long y5_lin_stamp_buf[8 * 65536];
 
 __device__ __forceinline__ void lgkm_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int BM, int BN, int WM, int WN, int NL, int S, int BK>
+// MODE bit 0: the epilogue stores straight from the accumulator registers (two 16-byte stores per MFMA tile and lane, no
+// barrier behind the K loop) instead of transposing the tile through LDS; bit 1: no stagger between the consumer halves.
+// Which form is faster depends on the layer (narrow tiles with short K loops prefer the direct form), so both are compiled
+// and the caller's autotuner decides.
+template <int BM, int BN, int WM, int WN, int NL, int S, int BK, int MODE>
 __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_lin3_kernel(const ConvArgs a) {
     typedef LinCfg<BM, BN, WM, WN, NL, S, BK> Cfg;
     constexpr int NWC = Cfg::NWC, WROW = Cfg::WROW, WSLOTS = WROW / 16;
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_lin3_kernel(const Co
                 }
             }
         }
-        lgkm_barrier();  // the consumers' barrier in front of the epilogue (LDS is reused there)
+        if constexpr (!(MODE & 1)) lgkm_barrier();  // the consumers' barrier in front of the epilogue (LDS is reused there)
         return;
     }
 
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_lin3_kernel(const Co
     // The two halves of the consumer waves (waves w and w + NWC/2 share a SIMD) run half a K-step apart: at every barrier
     // one of the two has its fragments in registers already and keeps the SIMD's matrix pipe busy while the other
     // waits for the LDS reads of its new stage.
-    const bool late = wave >= NWC / 2;
+    const bool late = !(MODE & 2) && wave >= NWC / 2;
     constexpr int KS = BK / 16, HK = KS / 2;
     if (late) lgkm_barrier();  // slot 0: nothing to do yet
     for (int kt = 0; kt < nk; ++kt) {
@@ -266,10 +270,40 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_lin3_kernel(const Co
     // wave's own WTM x WTN tile goes through a private LDS region (two 16-byte writes per MFMA tile) so that the global
     // stores are whole rows of WTN channels: 64 scattered 16-byte pieces per store instruction cost the texture unit
     // four times what the transposed form does.
+    const bool has_bias = a.bias != nullptr, has_scale = a.scale != nullptr;
+    if constexpr (MODE & 1) {
+#pragma unroll
+        for (int j = 0; j < RN; ++j) {
+            const int nl = wn * WTN + j * 32 + 16 * lh;
+            const int n = n0 + nl;
+            if (n >= a.Cout) continue;
+            const bool second = n + 8 < a.Cout;
+#pragma unroll
+            for (int i = 0; i < RM; ++i) {
+                const long long m = (long long)m0 + wm * WTM + i * 32 + lr;
+                if (m >= a.M) continue;
+                f16x4 h[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
+                    h[g] = post_op4_lds(v, nl + 4 * g, prm, BN, has_bias, has_scale, a.slope);
+                }
+                f16x8 lo = __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7);
+                f16x8 hi = __builtin_shufflevector(h[2], h[3], 0, 1, 2, 3, 4, 5, 6, 7);
+                if (a.res) {
+                    const f16* rp = a.res + (size_t)m * a.res_ld + n;
+                    lo += *reinterpret_cast<const f16x8*>(rp);
+                    if (second) hi += *reinterpret_cast<const f16x8*>(rp + 8);
+                }
+                f16* yp = a.y + (size_t)m * a.y_ld + n;
+                *reinterpret_cast<f16x8*>(yp) = lo;
+                if (second) *reinterpret_cast<f16x8*>(yp + 8) = hi;
+            }
+        }
+    } else {
     lgkm_barrier();  // every consumer is done with the halo and the ring: their space is reused below
     constexpr int EPW = WTN * 2 + 16;
     unsigned char* ep = smem + Cfg::HALO0 + wave * (WTM * EPW);
-    const bool has_bias = a.bias != nullptr, has_scale = a.scale != nullptr;
 #pragma unroll
     for (int j = 0; j < RN; ++j) {
         const int nl = wn * WTN + j * 32 + 16 * lh;
@@ -301,6 +335,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_lin3_kernel(const Co
             *reinterpret_cast<f16x8*>(a.y + (size_t)m * a.y_ld + n) = v;
         }
     }
+    }
 #ifdef Y5_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0 && blockIdx.x * NWC + wave < 65536) {
@@ -312,7 +347,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void conv_lin3_kernel(const Co
 
 constexpr int kNotApplicable = 1;  // launch_lin: the tile configuration does not take the shape (no error recorded)
 
-template <int BM, int BN, int WM, int WN, int NL, int S, int BK>
+template <int BM, int BN, int WM, int WN, int NL, int S, int BK, int MODE>
 int launch_lin(const ConvArgs& a0, hipStream_t s) {
     typedef LinCfg<BM, BN, WM, WN, NL, S, BK> Cfg;
     ConvArgs a = a0;
@@ -324,7 +359,7 @@ int launch_lin(const ConvArgs& a0, hipStream_t s) {
     a.lin_pieces = (int)((halo_bytes + 1023) / 1024);
     long long smem = (long long)Cfg::HALO0 + (long long)a.lin_pieces * 1024;
     const long long epi = (long long)Cfg::HALO0 + (long long)BM * BN / (BN / WN) * ((BN / WN) * 2 + 16);  // the waves' staged output tiles
-    if (epi > smem) smem = epi;
+    if (!(MODE & 1) && epi > smem) smem = epi;
     if (smem > 160 * 1024) return kNotApplicable;
     a.div_slots = make_fastdiv((unsigned)(a.lin_pitch / 16));
     a.lin_min = a.M;  // stride 1: as many input pixels as output pixels
@@ -337,11 +372,11 @@ int launch_lin(const ConvArgs& a0, hipStream_t s) {
     static std::atomic<unsigned long long> attr_set{0};  // one bit per device: the attribute is per function and device
     const unsigned long long bit = 1ull << y5_current_device();
     if (!(attr_set.load() & bit)) {
-        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lin3_kernel<BM, BN, WM, WN, NL, S, BK>),
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_lin3_kernel<BM, BN, WM, WN, NL, S, BK, MODE>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set.fetch_or(bit);
     }
-    hipLaunchKernelGGL((conv_lin3_kernel<BM, BN, WM, WN, NL, S, BK>), dim3((unsigned)total), dim3(Cfg::NT), (size_t)smem, s, a);
+    hipLaunchKernelGGL((conv_lin3_kernel<BM, BN, WM, WN, NL, S, BK, MODE>), dim3((unsigned)total), dim3(Cfg::NT), (size_t)smem, s, a);
     Y5_LAUNCH_CHECK("conv_lin3_kernel");
     return Y5_OK;
 }
@@ -350,12 +385,14 @@ struct LinVariant {
     int bn;
     int (*launch)(const ConvArgs&, hipStream_t);
 };
-#define Y5_LIN(BM, BN, WM, WN, NL, S, BK) {BN, &launch_lin<BM, BN, WM, WN, NL, S, BK>}
+#define Y5_LIN(BM, BN, WM, WN, NL, S, BK, MODE) {BN, &launch_lin<BM, BN, WM, WN, NL, S, BK, MODE>}
 const LinVariant kLin[] = {
-    Y5_LIN(256, 128, 4, 2, 4, 3, 64), Y5_LIN(256, 128, 2, 4, 4, 3, 64), Y5_LIN(128, 128, 2, 2, 4, 3, 64),
-    Y5_LIN(128, 128, 4, 2, 4, 3, 64), Y5_LIN(256, 64, 4, 2, 4, 3, 64),  Y5_LIN(256, 64, 4, 1, 2, 3, 64),
-    Y5_LIN(128, 64, 2, 2, 2, 3, 64),  Y5_LIN(128, 64, 4, 1, 2, 3, 64),  Y5_LIN(256, 32, 4, 1, 2, 3, 32),
-    Y5_LIN(128, 32, 4, 1, 2, 3, 32),  Y5_LIN(256, 64, 4, 2, 4, 3, 32),  Y5_LIN(256, 128, 4, 2, 4, 3, 32),
+    Y5_LIN(256, 128, 4, 2, 4, 3, 64, 0), Y5_LIN(256, 128, 4, 2, 4, 3, 64, 1), Y5_LIN(256, 128, 4, 2, 4, 3, 64, 3),
+    Y5_LIN(128, 128, 2, 2, 4, 3, 64, 0), Y5_LIN(128, 128, 4, 2, 4, 3, 64, 0), Y5_LIN(128, 128, 4, 2, 4, 3, 64, 1),
+    Y5_LIN(256, 64, 4, 2, 4, 3, 64, 0),  Y5_LIN(256, 64, 4, 2, 4, 3, 64, 3),  Y5_LIN(256, 64, 4, 1, 2, 3, 64, 3),
+    Y5_LIN(128, 64, 2, 2, 2, 3, 64, 3),  Y5_LIN(128, 64, 4, 1, 2, 3, 64, 3),  Y5_LIN(128, 64, 4, 2, 4, 3, 64, 1),
+    Y5_LIN(256, 32, 4, 1, 2, 3, 32, 3),  Y5_LIN(128, 32, 4, 1, 2, 3, 32, 3),  Y5_LIN(256, 64, 4, 2, 4, 3, 32, 3),
+    Y5_LIN(256, 64, 4, 2, 4, 3, 32, 0),  Y5_LIN(256, 32, 8, 1, 4, 3, 32, 1),  Y5_LIN(256, 128, 4, 2, 4, 3, 32, 0),
 };
 #undef Y5_LIN
 
