@@ -63,6 +63,8 @@ int y5_device_arch(char* buf, int n);
  * ------------------------------------------------------------------------------------------ */
 #define Y5_ACT_NONE 0
 #define Y5_ACT_LEAKY 1
+#define Y5_F16 0
+#define Y5_BF16 1
 
 typedef struct y5_conv_desc {
     const void* x;      /* input  (batch, h, w, cin) fp16, pixel pitch x_ld                         */
@@ -80,6 +82,10 @@ typedef struct y5_conv_desc {
     int32_t act;                /* Y5_ACT_*                                                         */
     float slope;                /* LeakyReLU negative slope (0.1 in the reference)                  */
     int32_t variant;            /* 0 = tile configuration chosen by rule; 1..y5_conv_num_variants() = explicit   */
+    int32_t dtype;              /* Y5_F16 (0) or Y5_BF16: element type of x, w, res and y.  bf16 (the reference's modules
+                                 * under .bfloat16(): same operations, bfloat16 roundings) is served by y5_conv_f16 with the
+                                 * im2col kernel family only: variant 0 or the first y5_conv_num_variants_bf16() ids; every
+                                 * other entry point that takes this descriptor wants Y5_F16 */
 } y5_conv_desc;
 
 int y5_conv_f16(const y5_conv_desc* d, y5_stream_t stream);
@@ -87,6 +93,8 @@ int y5_conv_f16(const y5_conv_desc* d, y5_stream_t stream);
  * loader-wave kernel families), for autotuning the `variant` field: time each id on the real shape and keep the
  * fastest; an id that does not apply to the shape returns Y5_EINVAL. */
 int y5_conv_num_variants(void);
+/* Number of tile configurations compiled for Y5_BF16 (ids 1..n of the variant field when dtype is Y5_BF16). */
+int y5_conv_num_variants_bf16(void);
 
 /* Two convolutions in one kernel: `first` (3x3, or 1x1 stride 1; all post-ops of y5_conv_f16 including the residual)
  * followed by `second`, a 1x1 stride-1 convolution of first's output (bias / scale+shift / activation, no residual):
@@ -164,6 +172,15 @@ int y5_maxpool_cascade_f16(const void* x, int x_ld, void* y, int y_ld, int y_ste
 int y5_upsample2x_f16(const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c, int mode,
                       y5_stream_t stream);
 
+/* The three pointwise kernels above that do arithmetic on the values (a maximum, a blend) for either 16-bit element type:
+ * dtype = Y5_F16 gives exactly the _f16 entry points, Y5_BF16 the same operations on bfloat16 tensors.  (Packing, nearest
+ * upsampling and channel copies only move 16-bit values: their _f16 entry points serve both types.) */
+int y5_maxpool_x16(const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c, int k, int dtype, y5_stream_t stream);
+int y5_maxpool_cascade_x16(const void* x, int x_ld, void* y, int y_ld, int y_step, int levels, int batch, int h, int w, int c, int k,
+                           int dtype, y5_stream_t stream);
+int y5_upsample2x_x16(const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c, int mode, int dtype,
+                      y5_stream_t stream);
+
 /* Copy a channel slice (batch*h*w pixels, c channels) between pitched buffers.
  * Replaces: Concat.forward  models/common.py:95-96 for operands that cannot be produced in place. */
 int y5_copy_channels_f16(const void* x, int x_ld, void* y, int y_ld, int64_t pixels, int c, y5_stream_t stream);
@@ -224,6 +241,8 @@ typedef struct y5_decode_desc {
     int32_t z_rows_total, z_row0;
     float stride;
     float anchor_wh[2 * Y5_MAX_ANCHORS]; /* pixel anchors (w,h) per anchor as stored in Detect.anchor_grid */
+    int32_t dtype;                       /* Y5_F16 or Y5_BF16: element type of head, x_out and z_out; the rounding order above
+                                          * then holds with bfloat16 in place of fp16 (Detect.forward under .bfloat16()) */
 } y5_decode_desc;
 
 int y5_detect_decode_f16(const y5_decode_desc* d, y5_stream_t stream);
@@ -336,6 +355,9 @@ int y5_plan_create(y5_plan** out);
 void y5_plan_destroy(y5_plan* p);
 /* Declare that device address `base` stands for external slot `slot` (0..15) while recording. */
 int y5_plan_bind_slot(y5_plan* p, int slot, const void* base, size_t bytes);
+/* Element type (Y5_F16 / Y5_BF16) of the pooling and upsampling ops recorded after this call; convolutions and decodes
+ * carry theirs in their descriptors.  A new plan records Y5_F16. */
+int y5_plan_set_dtype(y5_plan* p, int dtype);
 int y5_plan_add_conv(y5_plan* p, const y5_conv_desc* d);
 int y5_plan_add_focus_conv(y5_plan* p, const y5_conv_desc* d);
 int y5_plan_add_focus_conv_u8(y5_plan* p, const y5_conv_desc* d);

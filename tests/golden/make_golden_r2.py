@@ -4,6 +4,7 @@
   ensemble_yolov5s.npz  Ensemble.forward of two seeded, fused models (models/experimental.py:113-125), fp32
   halfblock_<name>.npz  the block fixtures' modules under .half() on the CPU: the reference's half-precision
                         evaluation tensor by tensor, which the oracle's precision='half' mode restates
+  bf16block_<name>.npz  the same under .bfloat16() (stored as fp32 values that are exact bfloat16 numbers)
   decode_bf16_64x96.npz Detect.forward under .bfloat16() on the CPU (rounding order of the bf16 decode)
 Run once in the build container:  python tests/golden/make_golden_r2.py
 Only data is written.
@@ -61,6 +62,22 @@ def main():
         mh = m.half()
         yh = mh(x.half())
         mg.save('halfblock_' + name, x=x.half(), y=yh, **mg.sd_arrays(mh))
+
+    def bf16block(name, ctor, cin, hw=(16, 16), seed=0, batch=2):
+        torch.manual_seed(seed)
+        m = ctor()
+        tu.initialize_weights(m)
+        mg.randomize_bn(m, seed + 1)
+        m.eval()
+        x = torch.randn(batch, cin, *hw, generator=torch.Generator().manual_seed(seed + 100))
+        mb = m.bfloat16()
+        yb = mb(x.bfloat16())
+        mg.save('bf16block_' + name, x=x.bfloat16().float(), y=yb.float(), **{k: v.float() for k, v in mg.sd_arrays(mb).items()})
+
+    bf16block('conv_k3s1', lambda: common.Conv(16, 32, 3, 1), 16)
+    bf16block('csp', lambda: common.BottleneckCSP(32, 32, n=2, shortcut=True), 32)
+    bf16block('spp', lambda: common.SPP(32, 32, (5, 9, 13)), 32, hw=(20, 20))
+    bf16block('focus', lambda: common.Focus(3, 32, 3), 3, hw=(32, 32))
 
     halfblock('conv_k3s1', lambda: common.Conv(16, 32, 3, 1), 16)
     halfblock('conv_k3s2_fused', lambda: common.Conv(24, 40, 3, 2), 24, fuse=True)

@@ -189,3 +189,47 @@ def test_half_mode_of_the_oracle_matches_the_reference_in_half_precision(name):
     worst = float((d / _ulp16(torch.maximum(got.abs(), want.abs()))).max())
     print('%s: %.4f identical, worst %.2f ulp' % (name, same, worst))
     assert same >= 0.99 and worst <= 3.0
+
+
+def _ulp_bf16(t):
+    """Spacing of bfloat16 at |t| (8 significant bits)."""
+    a = t.abs().clamp_min(2.0 ** -126)
+    return torch.pow(2.0, torch.floor(torch.log2(a)) - 7)
+
+
+BF16_BLOCKS = {'conv_k3s1': ('conv', 1), 'csp': ('csp', 2), 'spp': ('spp', None), 'focus': ('focus', None)}
+
+
+@pytest.mark.parametrize('name', sorted(BF16_BLOCKS))
+def test_bf16_mode_of_the_oracle_matches_the_reference_in_bfloat16(name):
+    """precision='bf16' against the reference's modules under .bfloat16() on the CPU (same rule as the half-mode pin: torch's
+    kernels accumulate in fp32 in their own order, a result next to a rounding boundary may come out one step apart)."""
+    z = util.golden('bf16block_' + name)
+    sd = {k: v.float() for k, v in util.sd_of(z).items()}
+    x = torch.from_numpy(z['x']).float()
+    want = torch.from_numpy(z['y']).float()
+    ops = y5ref._Ops('bf16')
+    kind, arg = BF16_BLOCKS[name]
+    if kind == 'conv':
+        got = y5ref.conv_block(ops, sd, 'model.0', x, arg)
+    elif kind == 'csp':
+        got = y5ref.bottleneck_csp(ops, sd, 'model.0', x, arg, True)
+    elif kind == 'spp':
+        got = y5ref.spp(ops, sd, 'model.0', x)
+    else:
+        got = y5ref.conv_block(ops, sd, 'model.0.conv', y5ref.focus_gather(x))
+    d = (got - want).abs()
+    same = float((d == 0).float().mean())
+    worst = float((d / _ulp_bf16(torch.maximum(got.abs(), want.abs()))).max())
+    print('%s: %.4f identical, worst %.2f ulp' % (name, same, worst))
+    assert same >= 0.98 and worst <= 3.0
+
+
+def test_bf16_decode_of_the_oracle_is_bit_exact():
+    """Detect.forward under .bfloat16(): the oracle's decode with a 16-bit dtype reproduces the fixture bit for bit."""
+    z = util.golden('decode_bf16_64x96')
+    raws = [torch.from_numpy(z['raw%d' % i]) for i in range(3)]
+    zr, xr = y5ref.detect_decode(raws, torch.from_numpy(z['anchor_grid']), torch.from_numpy(z['stride']), torch.bfloat16)
+    assert zr.dtype is torch.bfloat16 and torch.equal(zr.float(), torch.from_numpy(z['z']))
+    for i in range(3):
+        assert torch.equal(xr[i].float(), torch.from_numpy(z['x%d' % i]))

@@ -14,6 +14,7 @@ Y5_MAX_LEVELS = 4
 NMS_NOALLOC_BYTES = (16 << 20) + 4096  # Y5_NMS_NOALLOC_BYTES
 PLAN_SIDE, PLAN_JOIN = 1, 2
 ACT_NONE, ACT_LEAKY = 0, 1
+F16, BF16 = 0, 1  # y5_conv_desc.dtype / y5_decode_desc.dtype
 OK, EINVAL, EHIP, ENOMEM, EWORKSPACE = 0, -1, -2, -3, -4  # y5_status in include/y5hip.h
 OP_NAMES = {16: 'conv', 14: 'focus_conv', 15: 'focus_conv', 13: 'conv', 12: 'detect', 8: 'focus_conv', 9: 'decode', 10: 'focus_conv', 11: 'normalize', 1: 'conv', 2: 'pack', 3: 'maxpool', 4: 'upsample', 5: 'copy', 6: 'decode', 7: 'maxpool'}
 
@@ -25,7 +26,7 @@ class ConvDesc(C.Structure):
                 ('ho', C.c_int32), ('wo', C.c_int32), ('cout', C.c_int32), ('y_ld', C.c_int32), ('res_ld', C.c_int32),
                 ('ksize', C.c_int32), ('stride', C.c_int32), ('pad', C.c_int32),
                 ('kpad', C.c_int32), ('w_rows', C.c_int32), ('act', C.c_int32), ('slope', C.c_float),
-                ('variant', C.c_int32)]
+                ('variant', C.c_int32), ('dtype', C.c_int32)]
 
 
 class DecodeDesc(C.Structure):
@@ -33,7 +34,7 @@ class DecodeDesc(C.Structure):
                 ('head_ld', C.c_int32),
                 ('batch', C.c_int32), ('ny', C.c_int32), ('nx', C.c_int32), ('na', C.c_int32), ('no', C.c_int32),
                 ('z_rows_total', C.c_int32), ('z_row0', C.c_int32),
-                ('stride', C.c_float), ('anchor_wh', C.c_float * (2 * Y5_MAX_ANCHORS))]
+                ('stride', C.c_float), ('anchor_wh', C.c_float * (2 * Y5_MAX_ANCHORS)), ('dtype', C.c_int32)]
 
 
 class NmsDesc(C.Structure):
@@ -57,10 +58,14 @@ SIGNATURES = {
     'y5_stem_conv_u8': (_i, [C.POINTER(ConvDesc), _s]),
     'y5_normalize_u8_f16': (_i, [C.c_void_p, C.c_void_p, C.c_int64, _s]),
     'y5_conv_num_variants': (_i, []),
+    'y5_conv_num_variants_bf16': (_i, []),
     'y5_pack_image_f16': (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _s]),
     'y5_maxpool_f16': (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _s]),
     'y5_maxpool_cascade_f16': (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _s]),
     'y5_upsample2x_f16': (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _s]),
+    'y5_maxpool_x16': (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _s]),
+    'y5_maxpool_cascade_x16': (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _s]),
+    'y5_upsample2x_x16': (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _s]),
     'y5_copy_channels_f16': (_i, [_p, _i, _p, _i, C.c_int64, _i, _s]),
     'y5_conv_stats_f16': (_i, [C.POINTER(ConvDesc), _p, _i, _i, _i, _s]),
     'y5_bn_stats_rows': (_i, [C.c_int64, _i]),
@@ -86,6 +91,7 @@ SIGNATURES = {
     'y5_plan_create': (_i, [C.POINTER(_p)]),
     'y5_plan_destroy': (None, [_p]),
     'y5_plan_bind_slot': (_i, [_p, _i, _p, C.c_size_t]),
+    'y5_plan_set_dtype': (_i, [_p, _i]),
     'y5_plan_add_conv': (_i, [_p, C.POINTER(ConvDesc)]),
     'y5_plan_add_focus_conv': (_i, [_p, C.POINTER(ConvDesc)]),
     'y5_plan_add_focus_conv_u8': (_i, [_p, C.POINTER(ConvDesc)]),

@@ -66,6 +66,7 @@ extern "C" int y5_normalize_u8_f16(const void* x, void* y, int64_t n, y5_stream_
     return y5_launch_normalize_u8(x, y, n, static_cast<hipStream_t>(stream));
 }
 extern "C" int y5_conv_num_variants(void) { return y5_conv_variant_count(); }
+extern "C" int y5_conv_num_variants_bf16(void) { return y5_conv_bf16_variant_count(); }
 extern "C" int y5_pack_image_f16(const void* x, void* y, int batch, int c, int h, int w, int focus, int y_ld,
                                  y5_stream_t stream) {
     return y5_launch_pack_image(x, y, batch, c, h, w, focus, y_ld, static_cast<hipStream_t>(stream));
@@ -77,6 +78,17 @@ extern "C" int y5_maxpool_f16(const void* x, int x_ld, void* y, int y_ld, int ba
 extern "C" int y5_maxpool_cascade_f16(const void* x, int x_ld, void* y, int y_ld, int y_step, int levels, int batch, int h, int w,
                                       int c, int k, y5_stream_t stream) {
     return y5_launch_maxpool_cascade(x, x_ld, y, y_ld, y_step, levels, batch, h, w, c, k, static_cast<hipStream_t>(stream));
+}
+extern "C" int y5_maxpool_x16(const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c, int k, int dtype, y5_stream_t stream) {
+    return y5_launch_maxpool(x, x_ld, y, y_ld, batch, h, w, c, k, static_cast<hipStream_t>(stream), dtype);
+}
+extern "C" int y5_maxpool_cascade_x16(const void* x, int x_ld, void* y, int y_ld, int y_step, int levels, int batch, int h, int w, int c,
+                                      int k, int dtype, y5_stream_t stream) {
+    return y5_launch_maxpool_cascade(x, x_ld, y, y_ld, y_step, levels, batch, h, w, c, k, static_cast<hipStream_t>(stream), dtype);
+}
+extern "C" int y5_upsample2x_x16(const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c, int mode, int dtype,
+                                 y5_stream_t stream) {
+    return y5_launch_upsample2x(x, x_ld, y, y_ld, batch, h, w, c, mode, static_cast<hipStream_t>(stream), dtype);
 }
 extern "C" int y5_upsample2x_f16(const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c, int mode,
                                  y5_stream_t stream) {
@@ -171,12 +183,14 @@ struct Op {
     std::vector<PtrFix> fixes;
     double flops = 0.0, bytes = 0.0;
     int flags = 0;  // Y5_PLAN_SIDE / Y5_PLAN_JOIN
+    int dtype = Y5_F16;  // pointwise ops: element type
 };
 
 }  // namespace
 
 struct y5_plan {
     std::vector<Op> ops;
+    int dtype = Y5_F16;  // element type of the pointwise ops recorded from now on (y5_plan_set_dtype)
     SlotRange slots[16];
     // side stream for ops marked Y5_PLAN_SIDE and the events that order it against the caller's stream; created on
     // first use on the device that is current then
@@ -268,10 +282,10 @@ int run_op(const Op& op, hipStream_t s) {
         case Y5_OP_STEM_CONV_U8: return y5_launch_stem_conv(op.conv, s, true);
         case Y5_OP_NORMALIZE_U8: return y5_launch_normalize_u8(op.px, op.py, op.pixels, s);
         case Y5_OP_PACK: return y5_launch_pack_image(op.px, op.py, op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], s);
-        case Y5_OP_MAXPOOL: return y5_launch_maxpool(op.px, op.i[0], op.py, op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6], s);
+        case Y5_OP_MAXPOOL: return y5_launch_maxpool(op.px, op.i[0], op.py, op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6], s, op.dtype);
         case Y5_OP_MAXPOOL_CASCADE:
-            return y5_launch_maxpool_cascade(op.px, op.i[0], op.py, op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6], op.i[7], (int)op.pixels, s);
-        case Y5_OP_UPSAMPLE: return y5_launch_upsample2x(op.px, op.i[0], op.py, op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6], s);
+            return y5_launch_maxpool_cascade(op.px, op.i[0], op.py, op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6], op.i[7], (int)op.pixels, s, op.dtype);
+        case Y5_OP_UPSAMPLE: return y5_launch_upsample2x(op.px, op.i[0], op.py, op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6], s, op.dtype);
         case Y5_OP_COPY: return y5_launch_copy_channels(op.px, op.i[0], op.py, op.i[1], op.pixels, op.i[2], s);
         case Y5_OP_DECODE: return y5_launch_decode(op.dec, s);
         case Y5_OP_DECODE_MULTI: return y5_launch_decode_multi(op.decm, op.i[0], s);
@@ -323,6 +337,13 @@ extern "C" int y5_plan_bind_slot(y5_plan* p, int slot, const void* base, size_t 
     Y5_REQUIRE(base && bytes > 0, "plan_bind_slot: empty range");
     p->slots[slot].base = static_cast<const unsigned char*>(base);
     p->slots[slot].bytes = bytes;
+    return Y5_OK;
+}
+
+extern "C" int y5_plan_set_dtype(y5_plan* p, int dtype) {
+    Y5_REQUIRE(p, "plan_set_dtype: null plan");
+    Y5_REQUIRE(dtype == Y5_F16 || dtype == Y5_BF16, "plan_set_dtype: dtype %d not in {Y5_F16, Y5_BF16}", dtype);
+    p->dtype = dtype;
     return Y5_OK;
 }
 
@@ -378,6 +399,7 @@ static int add_pointwise(y5_plan* p, int kind, const void* x, void* y, const int
         for (int k = 0; k < ni; ++k) op.i[k] = iv[k];
         op.pixels = pixels;
         op.bytes = bytes;
+        op.dtype = p->dtype;
         note_ptr(p, op, 0, x);
         note_ptr(p, op, 1, y);
         p->ops.push_back(op);

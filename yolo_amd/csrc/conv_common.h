@@ -170,7 +170,7 @@ __device__ __forceinline__ void epi_store(float* prm, const EpiParams& p, int t,
     }
 }
 // Post-ops on four consecutive channels nl..nl+3 (workgroup-local, nl % 4 == 0) of one pixel, parameters from LDS.
-__device__ __forceinline__ f16x4 post_op4_lds(f32x4 v, int nl, const float* prm, int bn, bool has_bias, bool has_scale, float slope) {
+__device__ __forceinline__ f16x4 post_op4_lds_f16(f32x4 v, int nl, const float* prm, int bn, bool has_bias, bool has_scale, float slope) {
     if (has_bias) v += *reinterpret_cast<const f32x4*>(prm + nl);
     f16x4 h = __builtin_convertvector(v, f16x4);
     if (has_scale)
@@ -179,6 +179,20 @@ __device__ __forceinline__ f16x4 post_op4_lds(f32x4 v, int nl, const float* prm,
                                     f16x4);
     const f16x4 t = __builtin_convertvector(__builtin_convertvector(h, f32x4) * slope, f16x4);
     return __builtin_elementwise_max(h, t);
+}
+template <typename ET = f16>
+__device__ __forceinline__ typename Elem<ET>::v4 post_op4_lds(f32x4 v, int nl, const float* prm, int bn, bool has_bias, bool has_scale, float slope) {
+    if constexpr (sizeof(typename Elem<ET>::v4) == sizeof(f16x4) && __is_same(ET, f16)) {
+        return post_op4_lds_f16(v, nl, prm, bn, has_bias, has_scale, slope);
+    } else {
+        typedef Elem<ET> E;
+        if (has_bias) v += *reinterpret_cast<const f32x4*>(prm + nl);
+        typename E::v4 h = E::down(v);
+        if (has_scale) h = E::down(E::up(h) * *reinterpret_cast<const f32x4*>(prm + bn + nl) + *reinterpret_cast<const f32x4*>(prm + 2 * bn + nl));
+        const f32x4 hf = E::up(h);
+        const f32x4 tf = E::up(E::down(hf * slope));
+        return E::down(__builtin_elementwise_max(hf, tf));  // both operands are element-type values: the maximum is one of them
+    }
 }
 
 // Post-ops on four consecutive channels n..n+3 of one pixel (n % 4 == 0, n + 3 < Cout).

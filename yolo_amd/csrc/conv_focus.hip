@@ -393,6 +393,7 @@ int launch_stem(const FocusArgs& a, hipStream_t s) {
 }  // namespace
 
 int y5_launch_focus_conv(const y5_conv_desc& d, hipStream_t s, bool u8) {
+    Y5_REQUIRE(d.dtype == Y5_F16, "focus_conv: fp16 only (dtype %d)", d.dtype);
     Y5_REQUIRE(d.x && d.w && d.y, "focus_conv: null image, weight or output pointer");
     Y5_REQUIRE(d.cin == 3, "focus_conv: the image must have 3 channels (got %d)", d.cin);
     Y5_REQUIRE(d.ksize == 3 && d.stride == 1 && d.pad == 1, "focus_conv: only the 3x3 stride-1 pad-1 convolution is fused");
@@ -428,6 +429,7 @@ int y5_launch_focus_conv(const y5_conv_desc& d, hipStream_t s, bool u8) {
 }
 
 int y5_launch_stem_conv(const y5_conv_desc& d, hipStream_t s, bool u8) {
+    Y5_REQUIRE(d.dtype == Y5_F16, "stem_conv: fp16 only (dtype %d)", d.dtype);
     Y5_REQUIRE(d.x && d.w && d.y, "stem_conv: null image, weight or output pointer");
     Y5_REQUIRE(d.cin == 3, "stem_conv: the image must have 3 channels (got %d)", d.cin);
     Y5_REQUIRE(d.ksize == 3 && d.stride == 1 && d.pad == 1, "stem_conv: 3x3 stride-1 pad-1 only");

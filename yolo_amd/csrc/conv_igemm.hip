@@ -47,8 +47,13 @@ struct IgemmCfg {
 // the row: their products vanish).
 // CAT2 (1x1, DIRECT): the input is the channel concatenation [nearest-2x-upsampled x | x2] that is never built: K-steps
 // below Cin (a multiple of BK) fetch pixel (oy/2, ox/2) of the half-resolution x, the rest pixel (oy, ox) of x2.
-template <int BM, int BN, int WM, int WN, int KS, int S, int BK, bool DIRECT, bool UT = false, bool CAT2 = false>
+// ET: element type of activations and weights (f16 or bf16); everything up to the MFMA and from the post-ops on is
+// 16-bit data movement that does not care.
+template <int BM, int BN, int WM, int WN, int KS, int S, int BK, bool DIRECT, bool UT = false, bool CAT2 = false, typename ET = f16>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs a) {
+    typedef Elem<ET> E;
+    typedef typename E::v4 ev4;
+    typedef typename E::v8 ev8;
     static_assert(!UT || (KS == 3 && !DIRECT), "uniform-tap addressing is for 3x3 convolutions");
     static_assert(!CAT2 || DIRECT, "the two-source input is for 1x1 convolutions");
     constexpr int NW = WM * WN, NT = 64 * NW;
@@ -272,18 +277,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             const int coff = ((2 * ks + lh) ^ sw) << 4;
-            f16x8 xf[RM], wf[RN];
+            ev8 xf[RM], wf[RN];
 #pragma unroll
             for (int i = 0; i < RM; ++i)
-                xf[i] = *reinterpret_cast<const f16x8*>(A + (wm * WTM + i * 32 + lr) * ROW_BYTES + coff);
+                xf[i] = *reinterpret_cast<const ev8*>(A + (wm * WTM + i * 32 + lr) * ROW_BYTES + coff);
 #pragma unroll
             for (int j = 0; j < RN; ++j)
-                wf[j] = *reinterpret_cast<const f16x8*>(B + (wn * WTN + j * 32 + lr) * ROW_BYTES + coff);
+                wf[j] = *reinterpret_cast<const ev8*>(B + (wn * WTN + j * 32 + lr) * ROW_BYTES + coff);
 #pragma unroll
             for (int j = 0; j < RN; ++j)
 #pragma unroll
                 for (int i = 0; i < RM; ++i)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], xf[i], acc[j][i], 0, 0, 0);
+                    acc[j][i] = E::mfma(wf[j], xf[i], acc[j][i]);
         }
 #ifdef Y5_STAMPS
         const unsigned long long s3 = __builtin_amdgcn_s_memtime();
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
                 for (int i = 0; i < RM; ++i) {
                     const f32x4 v = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
                     const int ml = wm * WTM + i * 32 + lr;
-                    *reinterpret_cast<f16x4*>(smem + ml * EP + nl * 2) = post_op4_lds(v, nl, prm, BN, has_bias, has_scale, a.slope);
+                    *reinterpret_cast<ev4*>(smem + ml * EP + nl * 2) = post_op4_lds<ET>(v, nl, prm, BN, has_bias, has_scale, a.slope);
                 }
             }
         }
@@ -329,9 +334,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvArgs
             const int row = rr + p * RPP;
             const int m = m0 + row;
             if (m < a.M) {
-                f16x8 v = *reinterpret_cast<const f16x8*>(smem + row * EP + cc * 16);
-                if (a.res) v += *reinterpret_cast<const f16x8*>(a.res + (size_t)m * a.res_ld + n);
-                *reinterpret_cast<f16x8*>(a.y + (size_t)m * a.y_ld + n) = v;
+                ev8 v = *reinterpret_cast<const ev8*>(smem + row * EP + cc * 16);
+                if (a.res) v = E::add(v, *reinterpret_cast<const ev8*>(a.res + (size_t)m * a.res_ld + n));
+                *reinterpret_cast<ev8*>(a.y + (size_t)m * a.y_ld + n) = v;
                 if (want_stats) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
@@ -381,7 +386,7 @@ extern "C" int y5_debug_stamps(unsigned long long* dst, int n_waves) {
 namespace {
 #endif
 
-template <int BM, int BN, int WM, int WN, int S, int BK>
+template <int BM, int BN, int WM, int WN, int S, int BK, typename ET = f16>
 int launch_tile(const ConvArgs& a0, int ksize, bool direct, hipStream_t s) {
     ConvArgs a = a0;
     const long long tiles_m = (a.M + BM - 1) / BM;
@@ -395,13 +400,13 @@ int launch_tile(const ConvArgs& a0, int ksize, bool direct, hipStream_t s) {
     static std::atomic<unsigned long long> attr_set{0};  // one bit per device: the attribute is per function and device
     const unsigned long long attr_set_bit = 1ull << y5_current_device();
     if (!(attr_set.load() & attr_set_bit)) {
-        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, 3, S, BK, false>),
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, 3, S, BK, false, false, false, ET>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
-        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, 3, S, BK, false, true>),
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, 3, S, BK, false, true, false, ET>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
-        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, 1, S, BK, true>),
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, 1, S, BK, true, false, false, ET>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
-        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, 1, S, BK, false>),
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM, WN, 1, S, BK, false, false, false, ET>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
         attr_set.fetch_or(attr_set_bit);
     }
@@ -411,13 +416,13 @@ int launch_tile(const ConvArgs& a0, int ksize, bool direct, hipStream_t s) {
     const bool ut = ksize == 3 && nk_ut <= a.nk && !getenv("Y5_NO_UT");
     if (ut) a.nk = nk_ut;
     if (ut)
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 3, S, BK, false, true>), grid, block, Cfg::SMEM, s, a);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 3, S, BK, false, true, false, ET>), grid, block, Cfg::SMEM, s, a);
     else if (ksize == 3)
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 3, S, BK, false>), grid, block, Cfg::SMEM, s, a);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 3, S, BK, false, false, false, ET>), grid, block, Cfg::SMEM, s, a);
     else if (direct)
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1, S, BK, true>), grid, block, Cfg::SMEM, s, a);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1, S, BK, true, false, false, ET>), grid, block, Cfg::SMEM, s, a);
     else
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1, S, BK, false>), grid, block, Cfg::SMEM, s, a);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1, S, BK, false, false, false, ET>), grid, block, Cfg::SMEM, s, a);
     Y5_LAUNCH_CHECK("conv_igemm_kernel");
     return Y5_OK;
 }
@@ -486,13 +491,23 @@ const Variant kVariants[] = {
 };
 #undef Y5_V
 constexpr int kNumIgemm = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
+// The tile configurations compiled for bfloat16 tensors: every configuration the rule-based choice below can name, plus
+// two wide ones for the layers with many channels.
+#define Y5_VB(BM, BN, WM, WN, S, BK) {BM, BN, BK, S, &launch_tile<BM, BN, WM, WN, S, BK, bf16>}
+const Variant kVariantsBf[] = {
+    Y5_VB(128, 128, 2, 2, 2, 64), Y5_VB(128, 64, 2, 2, 3, 64),  Y5_VB(64, 128, 2, 2, 3, 64),  Y5_VB(64, 64, 2, 2, 3, 64),
+    Y5_VB(128, 32, 4, 1, 3, 64),  Y5_VB(128, 128, 2, 2, 3, 32), Y5_VB(128, 64, 2, 2, 4, 32),  Y5_VB(64, 128, 2, 2, 4, 32),
+    Y5_VB(64, 64, 2, 2, 4, 32),   Y5_VB(128, 32, 4, 1, 4, 32),  Y5_VB(256, 128, 4, 2, 2, 64), Y5_VB(128, 128, 2, 4, 3, 64),
+};
+#undef Y5_VB
+constexpr int kNumBf = (int)(sizeof(kVariantsBf) / sizeof(kVariantsBf[0]));
 constexpr int kNumHalo = 3;  // BN = 128, 64, 32
 constexpr int kNumWs = 3;    // weight-stationary 1x1 kernel, BN = 128, 64, 32
 constexpr int kNumWs3 = 2;   // weight-stationary 3x3 kernel for 32 / 64 input channels, BN = 64, 32
 
-int find_variant(int bm, int bn, int bk, int s) {
-    for (int i = 0; i < kNumIgemm; ++i)
-        if (kVariants[i].bm == bm && kVariants[i].bn == bn && kVariants[i].bk == bk && kVariants[i].s == s) return i;
+int find_variant(int bm, int bn, int bk, int s, const Variant* table = kVariants, int count = kNumIgemm) {
+    for (int i = 0; i < count; ++i)
+        if (table[i].bm == bm && table[i].bn == bn && table[i].bk == bk && table[i].s == s) return i;
     return 0;
 }
 
@@ -518,6 +533,12 @@ int y5_launch_conv(const y5_conv_desc& d, hipStream_t s, const Y5ConvStats* st) 
     Y5_REQUIRE(d.act == Y5_ACT_NONE || d.act == Y5_ACT_LEAKY, "conv: unknown activation %d", d.act);
     Y5_REQUIRE(d.act == Y5_ACT_NONE || (d.slope > 0.f && d.slope <= 1.f), "conv: LeakyReLU slope %g outside (0, 1]", (double)d.slope);
 
+    Y5_REQUIRE(d.dtype == Y5_F16 || d.dtype == Y5_BF16, "conv: dtype %d not in {Y5_F16, Y5_BF16}", d.dtype);
+    const bool bf = d.dtype == Y5_BF16;
+    if (bf) {
+        Y5_REQUIRE(!st, "conv: statistics are accumulated for fp16 tensors only");
+        if (d.variant > kNumBf) return y5_fail(Y5_EINVAL, "conv: variant %d is not compiled for bf16 (1..%d are)", d.variant, kNumBf);
+    }
     Y5_REQUIRE(d.variant >= 0 && d.variant <= y5_conv_variant_count(), "conv: variant %d out of range 0..%d", d.variant, y5_conv_variant_count());
     if (st) {
         Y5_REQUIRE(st->partials && st->rows > 0 && st->c > 0 && st->off >= 0 && st->off + d.cout <= st->c, "conv: statistics columns %d..+%d outside 0..%d (rows %d)", st->off, d.cout, st->c, st->rows);
@@ -544,7 +565,7 @@ int y5_launch_conv(const y5_conv_desc& d, hipStream_t s, const Y5ConvStats* st) 
         if (y5_try_conv_ws1x1(d, s, d.variant - kNumIgemm - kNumHalo, &rc)) return rc;
         return y5_fail(Y5_EINVAL, "conv: the weight-stationary variant %d does not apply to this shape", d.variant);
     }
-    if (d.variant > kNumIgemm || (d.variant == 0 && !st && !getenv("Y5_NO_HALO"))) {
+    if (!bf && (d.variant > kNumIgemm || (d.variant == 0 && !st && !getenv("Y5_NO_HALO")))) {
         int rc = Y5_OK;
         const int bn = d.variant == 0 ? 0 : (128 >> (d.variant - kNumIgemm - 1));
         if (y5_try_conv_halo(d, s, bn, &rc)) return rc;
@@ -595,12 +616,14 @@ int y5_launch_conv(const y5_conv_desc& d, hipStream_t s, const Y5ConvStats* st) 
         a.stats_rows = st->rows; a.stats_c = st->c; a.stats_off = st->off;
     }
 
+    const Variant* table = bf ? kVariantsBf : kVariants;
+    const int count = bf ? kNumBf : kNumIgemm;
     if (d.variant > 0) {
         // a tile reads BN whole weight rows: the packed weights (rows padded to a multiple of 128) must hold them
-        const int bn = kVariants[d.variant - 1].bn;
+        const int bn = table[d.variant - 1].bn;
         if ((long long)((d.cout + bn - 1) / bn) * bn > d.w_rows)
             return y5_fail(Y5_EINVAL, "conv: variant %d reads %d-row weight tiles, w_rows %d is too small for cout %d", d.variant, bn, d.w_rows, d.cout);
-        return kVariants[d.variant - 1].launch(a, d.ksize, direct, s);
+        return table[d.variant - 1].launch(a, d.ksize, direct, s);
     }
 
     // Rule-based choice. Channel width: the widest of {128, 64, 32} that wastes the fewest padded channels.
@@ -617,18 +640,20 @@ int y5_launch_conv(const y5_conv_desc& d, hipStream_t s, const Y5ConvStats* st) 
     const bool k32 = a.K < 256 && tail != 0 && tail <= 32;
     const int bm = small ? 64 : 128;
     int v;
-    if (k32) v = find_variant(bm, bn, 32, (bm == 128 && bn == 128) ? 3 : 4);
-    else v = find_variant(bm, bn, 64, (bm == 128 && bn == 128) ? 2 : 3);
-    return kVariants[v].launch(a, d.ksize, direct, s);
+    if (k32) v = find_variant(bm, bn, 32, (bm == 128 && bn == 128) ? 3 : 4, table, count);
+    else v = find_variant(bm, bn, 64, (bm == 128 && bn == 128) ? 2 : 3, table, count);
+    return table[v].launch(a, d.ksize, direct, s);
 }
 
 int y5_conv_variant_count() { return kNumIgemm + kNumHalo + kNumWs + kNumWs3 + y5_conv_lw_count() + y5_conv_lin_count(); }
 
 int y5_conv_cat2_variant_count() { return kNumCat2; }
+int y5_conv_bf16_variant_count() { return kNumBf; }
 
 // d: the convolution with x = the half-resolution tensor (batch, ho/2, wo/2, cin), h = ho, w_in = wo the OUTPUT
 // resolution; x2 (batch, ho, wo, cin2).  Weight rows hold K = cin + cin2 values, x's channels first.
 int y5_launch_conv_cat2(const y5_conv_desc& d, const void* x2, int x2_ld, int cin2, hipStream_t s) {
+    Y5_REQUIRE(d.dtype == Y5_F16, "conv_cat2: fp16 only (dtype %d)", d.dtype);
     Y5_REQUIRE(d.x && x2 && d.w && d.y, "conv_cat2: null tensor pointer");
     Y5_REQUIRE(d.ksize == 1 && d.stride == 1 && d.pad == 0, "conv_cat2: only 1x1 stride-1 convolutions");
     Y5_REQUIRE(d.batch > 0 && d.ho > 0 && d.wo > 0 && d.h == d.ho && d.w_in == d.wo, "conv_cat2: h, w_in must equal the output size %dx%d", d.ho, d.wo);

@@ -688,6 +688,7 @@ int y5_detect_variant_count() { return (int)(sizeof(kDetect) / sizeof(kDetect[0]
 
 // Detect level = 1x1 convolution (bias, no activation) + decode, one kernel.  conv.y is not written.
 int y5_launch_detect(const y5_conv_desc& c, const y5_decode_desc& d, int variant, hipStream_t s) {
+    Y5_REQUIRE(c.dtype == Y5_F16 && d.dtype == Y5_F16, "detect: fp16 only");
     Y5_REQUIRE(variant >= 0 && variant <= y5_detect_variant_count(), "detect: variant %d out of range 0..%d", variant, y5_detect_variant_count());
     Y5_REQUIRE(c.x && c.w && d.z_out, "detect: null tensor pointer");
     Y5_REQUIRE(c.ksize == 1 && c.stride == 1 && c.pad == 0, "detect: the head convolution is 1x1 stride 1");
@@ -766,6 +767,7 @@ int y5_try_conv_lw(const y5_conv_desc& d, hipStream_t s, int which, int* rc) {
 // A convolution followed by a 1x1 stride-1 convolution of its output, in one kernel (conv_lw_kernel, TAIL).
 // variant: 0 = the first tile shape that holds both channel counts, else 1..y5_conv_lw_count().
 int y5_launch_conv_chain(const y5_conv_desc& f, const y5_conv_desc& g, int keep_first, int variant, hipStream_t s) {
+    Y5_REQUIRE(f.dtype == Y5_F16 && g.dtype == Y5_F16, "conv chain: fp16 only");
     Y5_REQUIRE(variant >= 0 && variant <= y5_conv_lw_count(), "conv chain: variant %d out of range 0..%d", variant, y5_conv_lw_count());
     Y5_REQUIRE(f.x && f.w && g.w && g.y && (f.y || !keep_first), "conv chain: null tensor pointer");
     Y5_REQUIRE(f.ksize == 3 || (f.ksize == 1 && f.stride == 1), "conv chain: the first convolution is 3x3 or 1x1 stride 1");

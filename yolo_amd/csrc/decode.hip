@@ -16,10 +16,10 @@ __global__ __launch_bounds__(256) void sigmoid_kernel(const f16* __restrict__ x,
     if (i < n) y[i] = libm ? sigmoid_h_libm(x[i]) : sigmoid_h(x[i]);
 }
 
-template <bool VEC>
+template <bool VEC, typename ET>
 __global__ __launch_bounds__(kThreads) void detect_decode_kernel(const DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    decode_tile<VEC>(a, blockIdx.x, reinterpret_cast<f16*>(smem_raw));
+    decode_tile<VEC, ET>(a, blockIdx.x, reinterpret_cast<f16*>(smem_raw));
 }
 
 // All pyramid levels in one launch: the small levels (a few hundred workgroups) run beside the large one instead
@@ -30,12 +30,12 @@ struct DecodeMultiArgs {
     int n;
 };
 
-template <bool VEC>
+template <bool VEC, typename ET>
 __global__ __launch_bounds__(kThreads) void detect_decode_multi_kernel(const DecodeMultiArgs m) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     int l = 0;
     while (l + 1 < m.n && (int)blockIdx.x >= m.first_block[l + 1]) ++l;
-    decode_tile<VEC>(m.lv[l], blockIdx.x - m.first_block[l], reinterpret_cast<f16*>(smem_raw));
+    decode_tile<VEC, ET>(m.lv[l], blockIdx.x - m.first_block[l], reinterpret_cast<f16*>(smem_raw));
 }
 
 }  // namespace
@@ -66,10 +66,15 @@ int y5_launch_decode(const y5_decode_desc& d, hipStream_t s) {
     if (int rc = prepare_level(d, a, &lds_bytes, &vec)) return rc;
     if (int rc = check_head(d, a)) return rc;
     const dim3 grid((unsigned)(a.tiles_per_image * d.batch));
-    if (vec)
-        hipLaunchKernelGGL(detect_decode_kernel<true>, grid, dim3(kThreads), lds_bytes, s, a);
+    const bool bf = d.dtype == Y5_BF16;
+    if (vec && bf)
+        hipLaunchKernelGGL((detect_decode_kernel<true, bf16>), grid, dim3(kThreads), lds_bytes, s, a);
+    else if (vec)
+        hipLaunchKernelGGL((detect_decode_kernel<true, f16>), grid, dim3(kThreads), lds_bytes, s, a);
+    else if (bf)
+        hipLaunchKernelGGL((detect_decode_kernel<false, bf16>), grid, dim3(kThreads), lds_bytes, s, a);
     else
-        hipLaunchKernelGGL(detect_decode_kernel<false>, grid, dim3(kThreads), lds_bytes, s, a);
+        hipLaunchKernelGGL((detect_decode_kernel<false, f16>), grid, dim3(kThreads), lds_bytes, s, a);
     Y5_LAUNCH_CHECK("detect_decode_kernel");
     return Y5_OK;
 }
@@ -93,10 +98,16 @@ int y5_launch_decode_multi(const y5_decode_desc* d, int n, hipStream_t s) {
         Y5_REQUIRE(blocks < 0x7fffffffLL, "decode_multi: too many tiles");
     }
     m.first_block[n] = (int)blocks;
-    if (vec_all)
-        hipLaunchKernelGGL(detect_decode_multi_kernel<true>, dim3((unsigned)blocks), dim3(kThreads), lds_max, s, m);
+    const bool bf = d[0].dtype == Y5_BF16;
+    for (int l = 1; l < n; ++l) Y5_REQUIRE(d[l].dtype == d[0].dtype, "decode_multi: levels of different element types");
+    if (vec_all && bf)
+        hipLaunchKernelGGL((detect_decode_multi_kernel<true, bf16>), dim3((unsigned)blocks), dim3(kThreads), lds_max, s, m);
+    else if (vec_all)
+        hipLaunchKernelGGL((detect_decode_multi_kernel<true, f16>), dim3((unsigned)blocks), dim3(kThreads), lds_max, s, m);
+    else if (bf)
+        hipLaunchKernelGGL((detect_decode_multi_kernel<false, bf16>), dim3((unsigned)blocks), dim3(kThreads), lds_max, s, m);
     else
-        hipLaunchKernelGGL(detect_decode_multi_kernel<false>, dim3((unsigned)blocks), dim3(kThreads), lds_max, s, m);
+        hipLaunchKernelGGL((detect_decode_multi_kernel<false, f16>), dim3((unsigned)blocks), dim3(kThreads), lds_max, s, m);
     Y5_LAUNCH_CHECK("detect_decode_multi_kernel");
     return Y5_OK;
 }

@@ -17,34 +17,44 @@ struct DecodeArgs {
     float anchor_wh[2 * Y5_MAX_ANCHORS];
 };
 
-// sigmoid in fp32, rounded once to fp16 like a half tensor's .sigmoid().  The hardware exp2 / reciprocal form below
-// gives the same fp16 as 1/(1 + expf(-x)) with IEEE division for every one of the 65536 fp16 inputs (checked
-// exhaustively by the tests through y5_sigmoid_f16), at 4 instructions instead of ~25.
-__device__ __forceinline__ f16 sigmoid_h(f16 v) {
-    return (f16)__builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-(float)v * 1.44269504088896341f));
+// sigmoid in fp32, rounded once to the element type like a half / bfloat16 tensor's .sigmoid().  The hardware exp2 /
+// reciprocal form below gives the same fp16 as 1/(1 + expf(-x)) with IEEE division for every one of the 65536 fp16 inputs
+// (checked exhaustively by the tests through y5_sigmoid_f16), at 4 instructions instead of ~25.  bfloat16 keeps 8 bits,
+// so the IEEE form is used there: the decode is far from being bound by it.
+template <typename ET = f16>
+__device__ __forceinline__ ET sigmoid_h(ET v) {
+    if constexpr (__is_same(ET, f16)) return (f16)__builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-(float)v * 1.44269504088896341f));
+    else return (ET)(1.f / (1.f + expf(-(float)v)));
 }
 __device__ __forceinline__ f16 sigmoid_h_libm(f16 v) { return (f16)(1.f / (1.f + expf(-(float)v))); }
 
-// One decoded element. o: output slot within the anchor record, (gx, gy): cell, (aw, ah): anchor.
-__device__ __forceinline__ f16 decode_one(f16 raw, int o, float gx, float gy, float aw, float ah, float stride) {
-    const f16 s = sigmoid_h(raw);
+// One decoded element. o: output slot within the anchor record, (gx, gy): cell, (aw, ah): anchor.  Every tensor operation
+// of the reference's expression rounds to the element type, except the two that involve the fp32 grid / stride.
+template <typename ET = f16>
+__device__ __forceinline__ ET decode_one(ET raw, int o, float gx, float gy, float aw, float ah, float stride) {
+    const ET s = sigmoid_h<ET>(raw);
     if (o >= 4) return s;
-    const f16 two_s = (f16)((float)s * 2.f);  // exact doubling, kept as an fp16 op
+    const ET two_s = (ET)((float)s * 2.f);  // exact doubling, kept as an element-type op
     if (o < 2) {
-        const f16 c = (f16)((float)two_s - 0.5f);           // fp16 result of (y*2 - 0.5)
+        const ET c = (ET)((float)two_s - 0.5f);             // element-type result of (y*2 - 0.5)
         const float g = (float)c + (o == 0 ? gx : gy);      // promoted to fp32 by the fp32 grid
-        return (f16)(g * stride);                           // * fp32 stride, one rounding on store
+        return (ET)(g * stride);                            // * fp32 stride, one rounding on store
     }
-    const f16 sq = (f16)((float)two_s * (float)two_s);      // (y*2)**2 in fp16
-    return (f16)((float)sq * (o == 2 ? aw : ah));           // * fp16 anchor_grid, fp16 result
+    const ET sq = (ET)((float)two_s * (float)two_s);        // (y*2)**2 in the element type
+    return (ET)((float)sq * (o == 2 ? aw : ah));            // * anchor_grid (an element-type buffer), element-type result
 }
 
 // Decodes np <= TP consecutive pixels (from pix0, a multiple of TP) of image b whose head values lie in LDS at
 // tile[p * a.lds_ld + channel]; the caller has synchronised the workgroup (NTH threads) after filling the tile.
 // boxdec: (TP + 1) * na * 4 halfs of LDS for the decoded box slots.  Row TP of the tile may be read (never used).
-template <bool VEC, int NTH>
-__device__ __forceinline__ void decode_from_lds(const DecodeArgs& a, int b, int pix0, int np, f16* tile, f16* boxdec) {
+template <bool VEC, int NTH, typename ET = f16>
+__device__ __forceinline__ void decode_from_lds(const DecodeArgs& a, int b, int pix0, int np, f16* tile_, f16* boxdec_) {
     constexpr int kThreads = NTH;
+    typedef typename Elem<ET>::v8 ev8;
+    ET* tile = reinterpret_cast<ET*>(tile_);
+    ET* boxdec = reinterpret_cast<ET*>(boxdec_);
+    ET* const x_out = reinterpret_cast<ET*>(a.x_out);
+    ET* const z_out = reinterpret_cast<ET*>(a.z_out);
     const int npix_img = a.ny * a.nx;
 
     // The four box slots of every (pixel, anchor) are decoded first, densely (one value per thread), into a small LDS
@@ -56,7 +66,7 @@ __device__ __forceinline__ void decode_from_lds(const DecodeArgs& a, int b, int 
             const int p = pa / a.na, an = pa - p * a.na;
             const int pix = pix0 + p;
             const int gy = pix / a.nx, gx = pix - gy * a.nx;
-            boxdec[i] = decode_one(tile[p * a.lds_ld + an * a.no + o], o, (float)gx, (float)gy, a.anchor_wh[2 * an],
+            boxdec[i] = decode_one<ET>(tile[p * a.lds_ld + an * a.no + o], o, (float)gx, (float)gy, a.anchor_wh[2 * an],
                                    a.anchor_wh[2 * an + 1], a.stride);
         }
         __syncthreads();
@@ -67,7 +77,7 @@ __device__ __forceinline__ void decode_from_lds(const DecodeArgs& a, int b, int 
         const float aw = a.anchor_wh[2 * an], ah = a.anchor_wh[2 * an + 1];
         const long long xbase = (((long long)b * a.na + an) * npix_img + pix0) * a.no;
         const long long zbase = ((long long)b * a.z_rows_total + a.z_row0 + (long long)an * npix_img + pix0) * a.no;
-        const f16* col = tile + an * a.no;
+        const ET* col = tile + an * a.no;
         if (VEC) {
             // A window of 8 consecutive outputs lies in pixel p from slot o on and, past that pixel's last slot, in pixel
             // p + 1 from slot 0 on (prepare_level allows this path from no = 6 on).  Every element gets the sigmoid; the few windows that touch a pixel's four
@@ -76,13 +86,13 @@ __device__ __forceinline__ void decode_from_lds(const DecodeArgs& a, int b, int 
             for (int e0 = threadIdx.x * 8; e0 < run; e0 += kThreads * 8) {
                 const int p = e0 / a.no, o = e0 - p * a.no;
                 const int n1 = a.no - o;  // elements e >= n1 belong to pixel p + 1
-                const f16* src = col + p * a.lds_ld + o;
-                f16x8 raw, dec;
+                const ET* src = col + p * a.lds_ld + o;
+                ev8 raw, dec;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const f16 r = src[e + (e >= n1 ? skip : 0)];  // past the run's end: LDS behind the tile, never stored
+                    const ET r = src[e + (e >= n1 ? skip : 0)];  // past the run's end: LDS behind the tile, never stored
                     raw[e] = r;
-                    dec[e] = sigmoid_h(r);
+                    dec[e] = sigmoid_h<ET>(r);
                 }
                 if (o < 4 || n1 < 8) {
 #pragma unroll
@@ -93,30 +103,30 @@ __device__ __forceinline__ void decode_from_lds(const DecodeArgs& a, int b, int 
                     }
                 }
                 if (e0 + 8 <= run) {
-                    if (a.x_out) *reinterpret_cast<f16x8*>(a.x_out + xbase + e0) = raw;
-                    *reinterpret_cast<f16x8*>(a.z_out + zbase + e0) = dec;
+                    if (x_out) *reinterpret_cast<ev8*>(x_out + xbase + e0) = raw;
+                    *reinterpret_cast<ev8*>(z_out + zbase + e0) = dec;
                 } else {
                     for (int e = 0; e0 + e < run; ++e) {
-                        if (a.x_out) a.x_out[xbase + e0 + e] = raw[e];
-                        a.z_out[zbase + e0 + e] = dec[e];
+                        if (x_out) x_out[xbase + e0 + e] = raw[e];
+                        z_out[zbase + e0 + e] = dec[e];
                     }
                 }
             }
         } else {
             for (int e0 = threadIdx.x; e0 < run; e0 += kThreads) {
                 const int p = e0 / a.no, o = e0 - p * a.no;
-                const f16 r = col[p * a.lds_ld + o];
+                const ET r = col[p * a.lds_ld + o];
                 const int pix = pix0 + p;
                 const int gy = pix / a.nx, gx = pix - gy * a.nx;
-                if (a.x_out) a.x_out[xbase + e0] = r;
-                a.z_out[zbase + e0] = decode_one(r, o, (float)gx, (float)gy, aw, ah, a.stride);
+                if (x_out) x_out[xbase + e0] = r;
+                z_out[zbase + e0] = decode_one<ET>(r, o, (float)gx, (float)gy, aw, ah, a.stride);
             }
         }
     }
 }
 
 // One workgroup's work: tile `block` (TP pixels of one image) of the level described by a, staged from a.head.
-template <bool VEC>
+template <bool VEC, typename ET = f16>
 __device__ __forceinline__ void decode_tile(const DecodeArgs& a, int block, f16* tile) {
     const int b = block / a.tiles_per_image;
     const int tp = block - b * a.tiles_per_image;
@@ -132,12 +142,13 @@ __device__ __forceinline__ void decode_tile(const DecodeArgs& a, int block, f16*
             *reinterpret_cast<const uint4*>(src + (long long)p * a.head_ld + v * 8);
     }
     __syncthreads();
-    decode_from_lds<VEC, kThreads>(a, b, pix0, np, tile, tile + TP * a.lds_ld);
+    decode_from_lds<VEC, kThreads, ET>(a, b, pix0, np, tile, tile + TP * a.lds_ld);
 }
 
 // Validates one level and fills its kernel arguments; *vec says whether the 16-byte store path applies.
 inline int prepare_level(const y5_decode_desc& d, DecodeArgs& a, size_t* lds_bytes, bool* vec) {
     Y5_REQUIRE(d.z_out, "decode: null pointer");
+    Y5_REQUIRE(d.dtype == Y5_F16 || d.dtype == Y5_BF16, "decode: dtype %d not in {Y5_F16, Y5_BF16}", d.dtype);
     Y5_REQUIRE(d.batch > 0 && d.ny > 0 && d.nx > 0, "decode: empty tensor");
     Y5_REQUIRE(d.na >= 1 && d.na <= Y5_MAX_ANCHORS, "decode: na %d out of range 1..%d", d.na, Y5_MAX_ANCHORS);
     Y5_REQUIRE(d.no >= 5, "decode: no %d < 5", d.no);

@@ -72,8 +72,11 @@ __global__ __launch_bounds__(kThreads) void normalize_u8_kernel(const uint8_t* _
 }
 
 // One thread per (pixel, 8-channel vector).
+template <typename ET>
 __global__ __launch_bounds__(kThreads) void maxpool_kernel(const f16* __restrict__ x, int x_ld, f16* __restrict__ y, int y_ld,
                                                            int batch, int H, int W, int C8, int k) {
+    typedef Elem<ET> E;
+    typedef typename E::v8 v8;
     const long long total = (long long)batch * H * W * C8;
     const int r = k / 2;
     for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long long)gridDim.x * kThreads) {
@@ -83,26 +86,28 @@ __global__ __launch_bounds__(kThreads) void maxpool_kernel(const f16* __restrict
         const long long t = p / W;
         const int py = (int)(t % H);
         const long long b = t / H;
-        f16x8 m;
+        v8 m;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) m[e] = (f16)(-__builtin_inff());
+        for (int e = 0; e < 8; ++e) m[e] = (ET)(-__builtin_inff());
         const int y0 = py - r < 0 ? 0 : py - r, y1 = py + r >= H ? H - 1 : py + r;
         const int x0 = px - r < 0 ? 0 : px - r, x1 = px + r >= W ? W - 1 : px + r;
         for (int yy = y0; yy <= y1; ++yy) {
             const f16* row = x + ((b * H + yy) * (long long)W) * x_ld + c8 * 8;
             for (int xx = x0; xx <= x1; ++xx) {
-                const f16x8 v = *reinterpret_cast<const f16x8*>(row + (long long)xx * x_ld);
-                m = __builtin_elementwise_max(m, v);
+                const v8 v = *reinterpret_cast<const v8*>(row + (long long)xx * x_ld);
+                m = E::max8(m, v);
             }
         }
-        *reinterpret_cast<f16x8*>(y + p * y_ld + c8 * 8) = m;
+        *reinterpret_cast<v8*>(y + p * y_ld + c8 * 8) = m;
     }
 }
 
 // One thread per (output pixel, 8-channel vector).  Bilinear follows ATen's align_corners=False
 // rule: src = max(0, 0.5*(dst + 0.5) - 0.5), i1 = min(i0 + 1, in - 1), fp32 blend, one rounding.
+template <typename ET>
 __global__ __launch_bounds__(kThreads) void upsample2x_kernel(const f16* __restrict__ x, int x_ld, f16* __restrict__ y, int y_ld,
                                                               int batch, int H, int W, int C8, int mode) {
+    typedef typename Elem<ET>::v8 v8;
     const int Ho = 2 * H, Wo = 2 * W;
     const long long total = (long long)batch * Ho * Wo * C8;
     for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long long)gridDim.x * kThreads) {
@@ -113,74 +118,75 @@ __global__ __launch_bounds__(kThreads) void upsample2x_kernel(const f16* __restr
         const int oy = (int)(t % Ho);
         const long long b = t / Ho;
         const f16* xb = x + (b * H * (long long)W) * x_ld + c8 * 8;
-        f16x8 out;
+        v8 out;
         if (mode == 0) {
-            out = *reinterpret_cast<const f16x8*>(xb + ((long long)(oy >> 1) * W + (ox >> 1)) * x_ld);
+            out = *reinterpret_cast<const v8*>(xb + ((long long)(oy >> 1) * W + (ox >> 1)) * x_ld);
         } else {
             float sy = 0.5f * (oy + 0.5f) - 0.5f; if (sy < 0.f) sy = 0.f;
             float sx = 0.5f * (ox + 0.5f) - 0.5f; if (sx < 0.f) sx = 0.f;
             const int iy0 = (int)sy, ix0 = (int)sx;
             const int iy1 = iy0 + (iy0 < H - 1 ? 1 : 0), ix1 = ix0 + (ix0 < W - 1 ? 1 : 0);
             const float ly1 = sy - iy0, lx1 = sx - ix0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
-            const f16x8 v00 = *reinterpret_cast<const f16x8*>(xb + ((long long)iy0 * W + ix0) * x_ld);
-            const f16x8 v01 = *reinterpret_cast<const f16x8*>(xb + ((long long)iy0 * W + ix1) * x_ld);
-            const f16x8 v10 = *reinterpret_cast<const f16x8*>(xb + ((long long)iy1 * W + ix0) * x_ld);
-            const f16x8 v11 = *reinterpret_cast<const f16x8*>(xb + ((long long)iy1 * W + ix1) * x_ld);
+            const v8 v00 = *reinterpret_cast<const v8*>(xb + ((long long)iy0 * W + ix0) * x_ld);
+            const v8 v01 = *reinterpret_cast<const v8*>(xb + ((long long)iy0 * W + ix1) * x_ld);
+            const v8 v10 = *reinterpret_cast<const v8*>(xb + ((long long)iy1 * W + ix0) * x_ld);
+            const v8 v11 = *reinterpret_cast<const v8*>(xb + ((long long)iy1 * W + ix1) * x_ld);
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                out[e] = (f16)(ly0 * (lx0 * (float)v00[e] + lx1 * (float)v01[e]) + ly1 * (lx0 * (float)v10[e] + lx1 * (float)v11[e]));
+                out[e] = (ET)(ly0 * (lx0 * (float)v00[e] + lx1 * (float)v01[e]) + ly1 * (lx0 * (float)v10[e] + lx1 * (float)v11[e]));
         }
-        *reinterpret_cast<f16x8*>(y + p * y_ld + c8 * 8) = out;
+        *reinterpret_cast<v8*>(y + p * y_ld + c8 * 8) = out;
     }
 }
 
 // SPP in one launch: level l (l = 0..levels-1) is the k x k stride-1 max pool applied l+1 times, which equals
 // a single pool of size l*(k-1)+k (max composes exactly).  One workgroup owns one image and one 8-channel vector:
 // the H x W plane lives in LDS (two buffers), every level is read from LDS and written to LDS + global.
+template <typename ET>
 __global__ __launch_bounds__(kThreads) void maxpool_cascade_kernel(const f16* __restrict__ x, int x_ld, f16* __restrict__ y, int y_ld,
                                                                    int y_step, int levels, int H, int W, int C8, int k) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    f16x8* buf0 = reinterpret_cast<f16x8*>(smem_raw);
-    f16x8* buf1 = buf0 + H * W;
+    typename Elem<ET>::v8* buf0 = reinterpret_cast<typename Elem<ET>::v8*>(smem_raw);
+    typename Elem<ET>::v8* buf1 = buf0 + H * W;
     const int b = blockIdx.x / C8, c8 = blockIdx.x - b * C8;
     const int npix = H * W, r = k / 2;
     const long long pbase = (long long)b * npix;
-    for (int p = threadIdx.x; p < npix; p += kThreads) buf0[p] = *reinterpret_cast<const f16x8*>(x + (pbase + p) * x_ld + c8 * 8);
+    for (int p = threadIdx.x; p < npix; p += kThreads) buf0[p] = *reinterpret_cast<const typename Elem<ET>::v8*>(x + (pbase + p) * x_ld + c8 * 8);
     __syncthreads();
-    f16x8* src = buf0;
-    f16x8* dst = buf1;
+    typename Elem<ET>::v8* src = buf0;
+    typename Elem<ET>::v8* dst = buf1;
     for (int l = 0; l < levels; ++l) {
         for (int p = threadIdx.x; p < npix; p += kThreads) {
             const int py = p / W, px = p - py * W;
             const int y0 = py - r < 0 ? 0 : py - r, y1 = py + r >= H ? H - 1 : py + r;
             const int x0 = px - r < 0 ? 0 : px - r, x1 = px + r >= W ? W - 1 : px + r;
-            f16x8 m = src[y0 * W + x0];
+            typename Elem<ET>::v8 m = src[y0 * W + x0];
             for (int yy = y0; yy <= y1; ++yy)
-                for (int xx = x0; xx <= x1; ++xx) m = __builtin_elementwise_max(m, src[yy * W + xx]);
+                for (int xx = x0; xx <= x1; ++xx) m = Elem<ET>::max8(m, src[yy * W + xx]);
             dst[p] = m;
-            *reinterpret_cast<f16x8*>(y + (pbase + p) * y_ld + (long long)l * y_step + c8 * 8) = m;
+            *reinterpret_cast<typename Elem<ET>::v8*>(y + (pbase + p) * y_ld + (long long)l * y_step + c8 * 8) = m;
         }
         __syncthreads();
-        f16x8* t = src; src = dst; dst = t;
+        typename Elem<ET>::v8* t = src; src = dst; dst = t;
     }
 }
 
 // The same cascade, separable (a k x k max is a row max of column maxes) and VG 8-channel vectors wide: a workgroup
 // owns one image and VG adjacent vectors, so that global accesses are VG*16 contiguous bytes per pixel, and every
 // level costs 2k LDS reads per output instead of k*k.  Three LDS planes rotate: level input, row maxes, level output.
-template <int VG>
+template <int VG, typename ET>
 __global__ __launch_bounds__(kThreads) void maxpool_cascade_sep_kernel(const f16* __restrict__ x, int x_ld, f16* __restrict__ y,
                                                                        int y_ld, int y_step, int levels, int H, int W, int CG, int k) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int npix = H * W, n = npix * VG, r = k / 2;
-    f16x8* src = reinterpret_cast<f16x8*>(smem_raw);
-    f16x8* tmp = src + n;
-    f16x8* dst = tmp + n;
+    typename Elem<ET>::v8* src = reinterpret_cast<typename Elem<ET>::v8*>(smem_raw);
+    typename Elem<ET>::v8* tmp = src + n;
+    typename Elem<ET>::v8* dst = tmp + n;
     const int b = blockIdx.x / CG, c0 = (blockIdx.x - b * CG) * VG * 8;
     const long long pbase = (long long)b * npix;
     for (int i = threadIdx.x; i < n; i += kThreads) {
         const int p = i / VG, v = i - p * VG;
-        src[i] = *reinterpret_cast<const f16x8*>(x + (pbase + p) * x_ld + c0 + v * 8);
+        src[i] = *reinterpret_cast<const typename Elem<ET>::v8*>(x + (pbase + p) * x_ld + c0 + v * 8);
     }
     __syncthreads();
     for (int l = 0; l < levels; ++l) {
@@ -188,8 +194,8 @@ __global__ __launch_bounds__(kThreads) void maxpool_cascade_sep_kernel(const f16
             const int p = i / VG, v = i - p * VG;
             const int py = p / W, px = p - py * W;
             const int x0 = px - r < 0 ? 0 : px - r, x1 = px + r >= W ? W - 1 : px + r;
-            f16x8 m = src[(py * W + x0) * VG + v];
-            for (int xx = x0 + 1; xx <= x1; ++xx) m = __builtin_elementwise_max(m, src[(py * W + xx) * VG + v]);
+            typename Elem<ET>::v8 m = src[(py * W + x0) * VG + v];
+            for (int xx = x0 + 1; xx <= x1; ++xx) m = Elem<ET>::max8(m, src[(py * W + xx) * VG + v]);
             tmp[i] = m;
         }
         __syncthreads();
@@ -197,13 +203,13 @@ __global__ __launch_bounds__(kThreads) void maxpool_cascade_sep_kernel(const f16
             const int p = i / VG, v = i - p * VG;
             const int py = p / W, px = p - py * W;
             const int y0 = py - r < 0 ? 0 : py - r, y1 = py + r >= H ? H - 1 : py + r;
-            f16x8 m = tmp[(y0 * W + px) * VG + v];
-            for (int yy = y0 + 1; yy <= y1; ++yy) m = __builtin_elementwise_max(m, tmp[(yy * W + px) * VG + v]);
+            typename Elem<ET>::v8 m = tmp[(y0 * W + px) * VG + v];
+            for (int yy = y0 + 1; yy <= y1; ++yy) m = Elem<ET>::max8(m, tmp[(yy * W + px) * VG + v]);
             dst[i] = m;
-            *reinterpret_cast<f16x8*>(y + (pbase + p) * y_ld + (long long)l * y_step + c0 + v * 8) = m;
+            *reinterpret_cast<typename Elem<ET>::v8*>(y + (pbase + p) * y_ld + (long long)l * y_step + c0 + v * 8) = m;
         }
         __syncthreads();
-        f16x8* t = src; src = dst; dst = t;
+        typename Elem<ET>::v8* t = src; src = dst; dst = t;
     }
 }
 
@@ -242,29 +248,39 @@ int y5_launch_normalize_u8(const void* x, void* y, long long n, hipStream_t s) {
     return Y5_OK;
 }
 
-int y5_launch_maxpool(const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c, int k, hipStream_t s) {
+int y5_launch_maxpool(const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c, int k, hipStream_t s, int dtype) {
+    Y5_REQUIRE(dtype == Y5_F16 || dtype == Y5_BF16, "maxpool: dtype %d", dtype);
     Y5_REQUIRE(x && y, "maxpool: null pointer");
     Y5_REQUIRE(k % 2 == 1 && k >= 1 && k <= 13, "maxpool: k %d must be odd and <= 13", k);
     Y5_REQUIRE(c > 0 && c % 8 == 0 && x_ld % 8 == 0 && y_ld % 8 == 0 && x_ld >= c && y_ld >= c, "maxpool: channels/pitches must be multiples of 8");
     Y5_REQUIRE(batch > 0 && h > 0 && w > 0, "maxpool: empty tensor");
     Y5_REQUIRE(y5_aligned16(x) && y5_aligned16(y), "maxpool: pointers must be 16-byte aligned");
     const long long total = (long long)batch * h * w * (c / 8);
-    hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total)), dim3(kThreads), 0, s, static_cast<const f16*>(x), x_ld,
-                       static_cast<f16*>(y), y_ld, batch, h, w, c / 8, k);
+    if (dtype == Y5_BF16)
+        hipLaunchKernelGGL(maxpool_kernel<bf16>, dim3(grid_for(total)), dim3(kThreads), 0, s, static_cast<const f16*>(x), x_ld,
+                           static_cast<f16*>(y), y_ld, batch, h, w, c / 8, k);
+    else
+        hipLaunchKernelGGL(maxpool_kernel<f16>, dim3(grid_for(total)), dim3(kThreads), 0, s, static_cast<const f16*>(x), x_ld,
+                           static_cast<f16*>(y), y_ld, batch, h, w, c / 8, k);
     Y5_LAUNCH_CHECK("maxpool_kernel");
     return Y5_OK;
 }
 
 int y5_launch_upsample2x(const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c, int mode,
-                         hipStream_t s) {
+                         hipStream_t s, int dtype) {
+    Y5_REQUIRE(dtype == Y5_F16 || dtype == Y5_BF16, "upsample2x: dtype %d", dtype);
     Y5_REQUIRE(x && y, "upsample2x: null pointer");
     Y5_REQUIRE(mode == 0 || mode == 1, "upsample2x: mode %d not in {0 nearest, 1 bilinear}", mode);
     Y5_REQUIRE(c > 0 && c % 8 == 0 && x_ld % 8 == 0 && y_ld % 8 == 0 && x_ld >= c && y_ld >= c, "upsample2x: channels/pitches must be multiples of 8");
     Y5_REQUIRE(batch > 0 && h > 0 && w > 0, "upsample2x: empty tensor");
     Y5_REQUIRE(y5_aligned16(x) && y5_aligned16(y), "upsample2x: pointers must be 16-byte aligned");
     const long long total = (long long)batch * 4 * h * w * (c / 8);
-    hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for(total)), dim3(kThreads), 0, s, static_cast<const f16*>(x), x_ld,
-                       static_cast<f16*>(y), y_ld, batch, h, w, c / 8, mode);
+    if (dtype == Y5_BF16)
+        hipLaunchKernelGGL(upsample2x_kernel<bf16>, dim3(grid_for(total)), dim3(kThreads), 0, s, static_cast<const f16*>(x), x_ld,
+                           static_cast<f16*>(y), y_ld, batch, h, w, c / 8, mode);
+    else
+        hipLaunchKernelGGL(upsample2x_kernel<f16>, dim3(grid_for(total)), dim3(kThreads), 0, s, static_cast<const f16*>(x), x_ld,
+                           static_cast<f16*>(y), y_ld, batch, h, w, c / 8, mode);
     Y5_LAUNCH_CHECK("upsample2x_kernel");
     return Y5_OK;
 }
@@ -281,7 +297,9 @@ int y5_launch_copy_channels(const void* x, int x_ld, void* y, int y_ld, int64_t 
 }
 
 int y5_launch_maxpool_cascade(const void* x, int x_ld, void* y, int y_ld, int y_step, int levels, int batch, int h, int w, int c,
-                              int k, hipStream_t s) {
+                              int k, hipStream_t s, int dtype) {
+    Y5_REQUIRE(dtype == Y5_F16 || dtype == Y5_BF16, "maxpool_cascade: dtype %d", dtype);
+    const bool bf = dtype == Y5_BF16;
     Y5_REQUIRE(x && y, "maxpool_cascade: null pointer");
     Y5_REQUIRE(k % 2 == 1 && k >= 1 && k <= 13, "maxpool_cascade: k %d must be odd and <= 13", k);
     Y5_REQUIRE(levels >= 1 && levels <= 8, "maxpool_cascade: levels %d out of range 1..8", levels);
@@ -293,21 +311,33 @@ int y5_launch_maxpool_cascade(const void* x, int x_ld, void* y, int y_ld, int y_
     f16* yp = static_cast<f16*>(y);
     const size_t sep = (size_t)3 * h * w * 16;  // separable kernel: three planes per vector
     if (c % 16 == 0 && 2 * sep <= 64 * 1024) {
-        hipLaunchKernelGGL((maxpool_cascade_sep_kernel<2>), dim3((unsigned)(batch * (c / 16))), dim3(kThreads), 2 * sep, s, xp, x_ld, yp,
-                           y_ld, y_step, levels, h, w, c / 16, k);
+        if (bf)
+            hipLaunchKernelGGL((maxpool_cascade_sep_kernel<2, bf16>), dim3((unsigned)(batch * (c / 16))), dim3(kThreads), 2 * sep, s, xp, x_ld, yp,
+                               y_ld, y_step, levels, h, w, c / 16, k);
+        else
+            hipLaunchKernelGGL((maxpool_cascade_sep_kernel<2, f16>), dim3((unsigned)(batch * (c / 16))), dim3(kThreads), 2 * sep, s, xp, x_ld, yp,
+                               y_ld, y_step, levels, h, w, c / 16, k);
         Y5_LAUNCH_CHECK("maxpool_cascade_sep_kernel");
         return Y5_OK;
     }
     if (sep <= 64 * 1024) {
-        hipLaunchKernelGGL((maxpool_cascade_sep_kernel<1>), dim3((unsigned)(batch * (c / 8))), dim3(kThreads), sep, s, xp, x_ld, yp, y_ld,
-                           y_step, levels, h, w, c / 8, k);
+        if (bf)
+            hipLaunchKernelGGL((maxpool_cascade_sep_kernel<1, bf16>), dim3((unsigned)(batch * (c / 8))), dim3(kThreads), sep, s, xp, x_ld, yp, y_ld,
+                               y_step, levels, h, w, c / 8, k);
+        else
+            hipLaunchKernelGGL((maxpool_cascade_sep_kernel<1, f16>), dim3((unsigned)(batch * (c / 8))), dim3(kThreads), sep, s, xp, x_ld, yp, y_ld,
+                               y_step, levels, h, w, c / 8, k);
         Y5_LAUNCH_CHECK("maxpool_cascade_sep_kernel");
         return Y5_OK;
     }
     const size_t lds = (size_t)2 * h * w * 16;
     Y5_REQUIRE(lds <= 64 * 1024, "maxpool_cascade: %dx%d plane does not fit in LDS", h, w);
-    hipLaunchKernelGGL(maxpool_cascade_kernel, dim3((unsigned)(batch * (c / 8))), dim3(kThreads), lds, s, static_cast<const f16*>(x),
-                       x_ld, static_cast<f16*>(y), y_ld, y_step, levels, h, w, c / 8, k);
+    if (bf)
+        hipLaunchKernelGGL(maxpool_cascade_kernel<bf16>, dim3((unsigned)(batch * (c / 8))), dim3(kThreads), lds, s, static_cast<const f16*>(x),
+                           x_ld, static_cast<f16*>(y), y_ld, y_step, levels, h, w, c / 8, k);
+    else
+        hipLaunchKernelGGL(maxpool_cascade_kernel<f16>, dim3((unsigned)(batch * (c / 8))), dim3(kThreads), lds, s, static_cast<const f16*>(x),
+                           x_ld, static_cast<f16*>(y), y_ld, y_step, levels, h, w, c / 8, k);
     Y5_LAUNCH_CHECK("maxpool_cascade_kernel");
     return Y5_OK;
 }

@@ -12,8 +12,41 @@ typedef _Float16 f16;
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// The two 16-bit element types of the activation / weight tensors (y5_conv_desc.dtype: Y5_F16, Y5_BF16).  Both accumulate
+// in fp32; every tensor operation rounds its result to the element type once, like torch's half / bfloat16 kernels.
+template <typename T>
+struct Elem;
+template <>
+struct Elem<f16> {
+    typedef f16x4 v4;
+    typedef f16x8 v8;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ v4 down(f32x4 v) { return __builtin_convertvector(v, f16x4); }
+    static __device__ __forceinline__ f32x4 up(v4 h) { return __builtin_convertvector(h, f32x4); }
+    static __device__ __forceinline__ v8 add(v8 a, v8 b) { return a + b; }
+    static __device__ __forceinline__ v8 max8(v8 a, v8 b) { return __builtin_elementwise_max(a, b); }
+};
+template <>
+struct Elem<bf16> {
+    typedef bf16x4 v4;
+    typedef bf16x8 v8;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ v4 down(f32x4 v) { return __builtin_convertvector(v, bf16x4); }
+    static __device__ __forceinline__ f32x4 up(v4 h) { return __builtin_convertvector(h, f32x4); }
+    static __device__ __forceinline__ v8 add(v8 a, v8 b) {
+        return __builtin_convertvector(__builtin_convertvector(a, f32x8) + __builtin_convertvector(b, f32x8), bf16x8);
+    }
+    static __device__ __forceinline__ v8 max8(v8 a, v8 b) {
+        return __builtin_convertvector(__builtin_elementwise_max(__builtin_convertvector(a, f32x8), __builtin_convertvector(b, f32x8)), bf16x8);
+    }
+};
 
 // Records a failure for y5_last_error() and returns `code`.
 int y5_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
@@ -66,6 +99,7 @@ int y5_launch_detect(const y5_conv_desc& c, const y5_decode_desc& d, int variant
 int y5_detect_variant_count();
 int y5_launch_conv_chain(const y5_conv_desc& f, const y5_conv_desc& g, int keep_first, int variant, hipStream_t s);
 int y5_conv_variant_count();
+int y5_conv_bf16_variant_count();
 int y5_launch_conv_cat2(const y5_conv_desc& d, const void* x2, int x2_ld, int cin2, hipStream_t s);
 int y5_conv_cat2_variant_count();
 // Focus gather + 3x3 convolution from the NCHW image (conv_focus.hip); d.x is the image, d.cin its 3 channels.
@@ -73,11 +107,11 @@ int y5_launch_focus_conv(const y5_conv_desc& d, hipStream_t s, bool u8 = false);
 int y5_launch_stem_conv(const y5_conv_desc& d, hipStream_t s, bool u8 = false);
 int y5_launch_normalize_u8(const void* x, void* y, long long n, hipStream_t s);
 int y5_launch_pack_image(const void* x, void* y, int batch, int c, int h, int w, int focus, int y_ld, hipStream_t s);
-int y5_launch_maxpool(const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c, int k, hipStream_t s);
+int y5_launch_maxpool(const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c, int k, hipStream_t s, int dtype = Y5_F16);
 int y5_launch_maxpool_cascade(const void* x, int x_ld, void* y, int y_ld, int y_step, int levels, int batch, int h, int w, int c,
-                              int k, hipStream_t s);
+                              int k, hipStream_t s, int dtype = Y5_F16);
 int y5_launch_upsample2x(const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c, int mode,
-                         hipStream_t s);
+                         hipStream_t s, int dtype = Y5_F16);
 int y5_launch_copy_channels(const void* x, int x_ld, void* y, int y_ld, int64_t pixels, int c, hipStream_t s);
 int y5_launch_decode(const y5_decode_desc& d, hipStream_t s);
 int y5_launch_decode_multi(const y5_decode_desc* d, int n, hipStream_t s);

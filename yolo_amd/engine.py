@@ -107,7 +107,7 @@ def _has_hooks(model):
 
 
 def eligible(model, x):
-    """True when this forward may run on the HIP engine: inference mode on a GPU in fp16, no autograd,
+    """True when this forward may run on the HIP engine: inference mode on a GPU in fp16 or bf16, no autograd,
     no module hooks (the pruning / FLOP-counting tools attach hooks and need the torch modules to run),
     Detect.export off, 4-d input whose height and width are multiples of the largest stride."""
     if _DISABLED[0] or model.training or torch.is_grad_enabled():
@@ -119,7 +119,7 @@ def eligible(model, x):
         # itself, inside the first kernel where it can; only meaningful for a half-precision model
         if next(model.parameters()).dtype is not torch.float16:
             return False
-    elif x.dtype is not torch.float16:
+    elif x.dtype not in (torch.float16, torch.bfloat16) or next(model.parameters()).dtype is not x.dtype:
         return False
     from yolo_amd.models.yolo import Detect
     head = model.model[-1]
@@ -207,7 +207,7 @@ def _conv_geometry(conv):
     return k[0], s[0]
 
 
-def pack_conv_weight(weights, segs, device):
+def pack_conv_weight(weights, segs, device, dtype=torch.float16):
     """Row groups [(weight (c, Cin_logical, k, k), padded rows)] -> fp16 [rows256][kpad64];
     K index (r*k + q)*cin_pad + c following the input tensor's channel `segs`.  Returns (packed, kpad, rows)."""
     k = weights[0][0].shape[-1]
@@ -217,13 +217,13 @@ def pack_conv_weight(weights, segs, device):
     rows = (total_rows + 255) // 256 * 256   # whole 256-row weight tiles for the widest kernel variant
     kk = k * k * cin_pad
     kpad = (kk + 63) // 64 * 64
-    packed = torch.zeros(rows, kpad, dtype=torch.float16, device=device)
+    packed = torch.zeros(rows, kpad, dtype=dtype, device=device)
     r0 = 0
     for weight, rpad in weights:
         cout, cin = weight.shape[:2]
         if cin != cin_log or weight.shape[-1] != k:
             raise Unsupported('conv expects %d input channels, tensor has %d' % (cin, cin_log))
-        w = weight.detach().to(torch.float16).permute(0, 2, 3, 1)  # (Cout, k, k, Cin)
+        w = weight.detach().to(dtype).permute(0, 2, 3, 1)  # (Cout, k, k, Cin)
         view = packed[r0:r0 + cout, :kk].view(cout, k, k, cin_pad)
         src = dst = 0
         for c, pc in segs:
@@ -241,6 +241,11 @@ class Plan:
         """module: a models.yolo.Model, or with block=True a single Conv / Bottleneck / BottleneckCSP / SPP / Focus."""
         self.lib = _lib.lib()
         self.device = x.device
+        # element type of every activation and weight of the plan: fp16, or bf16 (then only the kernels compiled for it are
+        # recorded: the im2col convolution family, the stand-alone decode, pooling / upsampling; no fused first layer, no
+        # folded Upsample + Concat, no chained or Detect-fused convolutions)
+        self.dtype = torch.bfloat16 if x.dtype is torch.bfloat16 else torch.float16
+        self.bf16 = self.dtype is torch.bfloat16
         self.batch, self.cin, self.h, self.w = x.shape
         self.keep = []          # tensors the plan's device pointers refer to
         self.labels = []        # one human-readable label per op
@@ -249,6 +254,8 @@ class Plan:
         handle = C.c_void_p()
         _lib.check(self.lib.y5_plan_create(C.byref(handle)))
         self.handle = handle
+        if self.bf16:
+            _lib.check(self.lib.y5_plan_set_dtype(handle, _lib.BF16))
         try:
             if block:
                 self._build_block(module, x)
@@ -272,7 +279,7 @@ class Plan:
     # ------------------------------------------------------------------ allocation helpers
     def _new_act(self, batch, h, w, segs):
         c = sum(p for _, p in segs)
-        buf = torch.zeros(batch * h * w * c, dtype=torch.float16, device=self.device)
+        buf = torch.zeros(batch * h * w * c, dtype=self.dtype, device=self.device)
         self.keep.append(buf)
         return Act(buf, 0, c, batch, h, w, segs)
 
@@ -283,7 +290,7 @@ class Plan:
         return out
 
     def _pack_weight(self, weights, segs):
-        packed, kpad, rows = pack_conv_weight(weights, segs, self.device)
+        packed, kpad, rows = pack_conv_weight(weights, segs, self.device, self.dtype)
         self.keep.append(packed)
         return packed, kpad, rows
 
@@ -294,8 +301,8 @@ class Plan:
         image: the NCHW input batch when this is Focus's convolution read straight from it (x then only describes
         the space-to-depth tensor that is never built)."""
         for w, _ in weights:
-            if w.dtype is not torch.float16 or w.device != self.device:
-                raise Unsupported('conv weights must be fp16 on the input device')
+            if w.dtype is not self.dtype or w.device != self.device:
+                raise Unsupported("conv weights must have the input's element type and device")
         if [p for _, p in weights] != [p for _, p in out.segs] or [w.shape[0] for w, _ in weights] != [c for c, _ in out.segs]:
             raise Unsupported('conv output slice mismatch')
         cat2 = None
@@ -309,6 +316,7 @@ class Plan:
             raise Unsupported('conv output size mismatch')
         packed, kpad, rows = self._pack_weight(weights, x.segs)
         d = _lib.ConvDesc()
+        d.dtype = _lib.BF16 if self.bf16 else _lib.F16
         d.x, d.w, d.y = (x.ptr if image is None else image.data_ptr()), packed.data_ptr(), out.ptr
         cpad = out.c_pad
         if bias is not None:
@@ -429,7 +437,7 @@ class Plan:
         process; Y5_AUTOTUNE=0 keeps the rule-based choice (variant 0)."""
         if os.environ.get('Y5_AUTOTUNE', '1') == '0':
             return 0
-        key = (d.batch, d.h, d.w_in, d.cin, d.x_ld, d.cout, d.y_ld, d.ksize, d.stride, bool(d.res), bool(d.bias), bool(d.scale))
+        key = (d.batch, d.h, d.w_in, d.cin, d.x_ld, d.cout, d.y_ld, d.ksize, d.stride, bool(d.res), bool(d.bias), bool(d.scale), d.dtype)
         self._last_key = key
         if key in _TUNED:
             return _TUNED[key]
@@ -437,7 +445,8 @@ class Plan:
         stream = _lib.current_stream()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         timed = []
-        for v in range(self.lib.y5_conv_num_variants() + 1):
+        nvar = self.lib.y5_conv_num_variants_bf16() if self.bf16 else self.lib.y5_conv_num_variants()
+        for v in range(nvar + 1):
             d.variant = v
             if self.lib.y5_conv_f16(C.byref(d), stream) != 0:
                 continue  # configuration does not apply to this shape
@@ -505,7 +514,7 @@ class Plan:
         B, cin, H, W = image.shape
         k, s = _conv_geometry(m.conv.conv)
         segs = [(4 * cin, pad8(4 * cin))]
-        if cin == 3 and (k, s) == (3, 1) and out.c_pad <= 96 and os.environ.get('Y5_FOCUS_FUSE', '1') != '0':
+        if cin == 3 and (k, s) == (3, 1) and out.c_pad <= 96 and not self.bf16 and os.environ.get('Y5_FOCUS_FUSE', '1') != '0':
             shape_only = Act(None, 0, segs[0][1], B, H // 2, W // 2, segs)
             self._conv_block(name, m.conv, shape_only, out, image=image)
             return
@@ -590,7 +599,7 @@ class Plan:
                     consumers[src_idx].append(i)
         self.lazy_cat = {}   # concat layer index -> (upsample layer index, skip layer index)
         self.lazy_up = {}    # upsample layer index -> its source layer index
-        if os.environ.get('Y5_CAT2_FUSE', '1') != '0':
+        if os.environ.get('Y5_CAT2_FUSE', '1') != '0' and not self.bf16:
             for i, m in enumerate(layers):
                 if not isinstance(m, common.Concat) or not isinstance(m.f, (list, tuple)) or len(m.f) != 2:
                     continue
@@ -660,7 +669,7 @@ class Plan:
                 self._focus(name, m, image, out)
             elif isinstance(m, common.Conv):
                 if (i == 0 and self.cin == 3 and _conv_geometry(m.conv) == (3, 1) and pad8(c_log) <= 64 and W % 2 == 0
-                        and os.environ.get('Y5_STEM_FUSE', '1') != '0'):
+                        and not self.bf16 and os.environ.get('Y5_STEM_FUSE', '1') != '0'):
                     # first-layer 3x3 conv straight from the NCHW (fp16 or uint8) image: no packed copy of the image
                     shape_only = Act(None, 0, 8, B, H, W, [(3, 8)])
                     out = self._out_for(i, B, h, w, c_log)
@@ -803,7 +812,7 @@ class Plan:
         bots = list(m.m)
         # The last Bottleneck's cv2 (+ residual) and cv3 as one kernel when both widths fit one tile: the Bottleneck's
         # output, which only cv3 reads, is never written.
-        chain = (len(bots) > 0 and os.environ.get('Y5_CHAIN_FUSE', '1') != '0' and _conv_geometry(m.cv3) == (1, 1)
+        chain = (len(bots) > 0 and not self.bf16 and os.environ.get('Y5_CHAIN_FUSE', '1') != '0' and _conv_geometry(m.cv3) == (1, 1)
                  and max(pad8(bots[-1].cv2.conv.out_channels), pad8(c3)) <= 256)
         # Between Bottlenecks the same kernel serves m[i].cv2 (+ residual) -> m[i+1].cv1 with the first result kept (the
         # next shortcut needs it): the 1x1 then reads its input from LDS instead of HBM.  Measured per shape like the rest.
@@ -936,17 +945,18 @@ class Plan:
         rows = [na * f.h * f.w for f in feats]
         self.z_shape = (B, sum(rows), no)
         self.x_shapes = [(B, na, f.h, f.w, no) for f in feats]
-        z = torch.zeros(self.z_shape, dtype=torch.float16, device=self.device)
-        xs = [torch.zeros(s, dtype=torch.float16, device=self.device) for s in self.x_shapes]
+        z = torch.zeros(self.z_shape, dtype=self.dtype, device=self.device)
+        xs = [torch.zeros(s, dtype=self.dtype, device=self.device) for s in self.x_shapes]
         self.keep += [z] + xs
         _lib.check(self.lib.y5_plan_bind_slot(self.handle, 1, z.data_ptr(), z.numel() * 2))
         for i, t in enumerate(xs):
             _lib.check(self.lib.y5_plan_bind_slot(self.handle, 2 + i, t.data_ptr(), t.numel() * 2))
         row0 = 0
-        anchor_grid = m.anchor_grid.detach().float().cpu().view(m.nl, na, 2)
+        anchor_grid = m.anchor_grid.detach().float().cpu().view(m.nl, na, 2)  # element-type values (the buffer follows .half() / .bfloat16())
 
         def decode_desc(i, f, row0):
             d = _lib.DecodeDesc()
+            d.dtype = _lib.BF16 if self.bf16 else _lib.F16
             d.x_out, d.z_out = xs[i].data_ptr(), z.data_ptr()
             d.batch, d.ny, d.nx, d.na, d.no = B, f.h, f.w, na, no
             d.z_rows_total, d.z_row0 = self.z_shape[1], row0
@@ -958,7 +968,7 @@ class Plan:
 
         # Every level as ONE kernel (head conv with the decode as its epilogue) when all of them qualify and none was
         # already recorded on the side stream; otherwise head convs + one decode launch.
-        if not self.head_bufs and os.environ.get('Y5_DETECT_FUSE', '1') != '0':
+        if not self.head_bufs and not self.bf16 and os.environ.get('Y5_DETECT_FUSE', '1') != '0':
             ops, r0 = [], 0
             for i, f in enumerate(feats):
                 op = self._detect_fused(m, i, f, decode_desc(i, f, r0))
@@ -1000,16 +1010,16 @@ class Plan:
         return arr
 
     def run(self, x):
-        z = torch.empty(self.z_shape, dtype=torch.float16, device=self.device)
-        xs = [torch.empty(s, dtype=torch.float16, device=self.device) for s in self.x_shapes]
+        z = torch.empty(self.z_shape, dtype=self.dtype, device=self.device)
+        xs = [torch.empty(s, dtype=self.dtype, device=self.device) for s in self.x_shapes]
         ext = self._ext(x, z, xs)
         _lib.check(self.lib.y5_plan_run(self.handle, ext, len(ext), _lib.current_stream()))
         return z, xs
 
     def profile(self, x):
         """Per-op device milliseconds (hipEvent pairs on the current stream) with kind/FLOPs/bytes/labels."""
-        z = torch.empty(self.z_shape, dtype=torch.float16, device=self.device)
-        xs = [torch.empty(s, dtype=torch.float16, device=self.device) for s in self.x_shapes]
+        z = torch.empty(self.z_shape, dtype=self.dtype, device=self.device)
+        xs = [torch.empty(s, dtype=self.dtype, device=self.device) for s in self.x_shapes]
         ext = self._ext(x, z, xs)
         n = self.lib.y5_plan_num_ops(self.handle)
         ms = (C.c_float * n)()
