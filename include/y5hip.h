@@ -108,6 +108,37 @@ int y5_conv_num_variants_bf16(void);
 int y5_conv_chain_f16(const y5_conv_desc* first, const y5_conv_desc* second, int keep_first, int variant, y5_stream_t stream);
 int y5_conv_chain_num_variants(void);
 
+/* BottleneckCSP with ONE Bottleneck as one kernel: every intermediate tensor of the block stays on chip.
+ * Replaces: BottleneckCSP.forward  models/common.py:59-62 with n = 1, i.e. the five convolutions
+ *     y1 = cv3(m[0](cv1(x))),  m[0](t) = t + m[0].cv2(m[0].cv1(t))  (Bottleneck.forward models/common.py:43; without the
+ *     y2 = cv2(x)                                                      addition when shortcut == 0)
+ *     out = cv4(act(bn(cat(y1, y2))))
+ * Each stage carries the post-ops of y5_conv_f16 (bias / scale+shift / LeakyReLU, each rounded to fp16), so the result
+ * equals the layer-by-layer evaluation up to the fp32 summation order:
+ *     cv12   rows [0, ch) = cv1 with its own BatchNorm or bias; rows [ch, 2 ch) = cv2 with the second half of the concat
+ *            BatchNorm;   m_cv1, m_cv2 = the Bottleneck's convolutions (m_cv2 is 3x3, k = (r*3+q)*ch + c);
+ *     cv3    with the first half of the concat BatchNorm;   cv4 reads [y1 | y2].
+ * Compiled for c1 = 64, ch = 32, c2 = 64 (yolov5s layer 2), h % 8 == 0, w % 32 == 0; Y5_EINVAL otherwise.  Every stage
+ * is followed by LeakyReLU(slope). */
+typedef struct y5_csp_stage {
+    const void* w;      /* fp16 [rows][w_ld], row n = output channel n, zero padded */
+    const float* bias;  /* fp32 per output channel, or NULL */
+    const float* scale; /* fp32 per output channel, or NULL */
+    const float* shift; /* required when scale != NULL */
+    int w_ld;           /* row pitch in elements */
+    int reserved;
+} y5_csp_stage;
+typedef struct y5_csp_desc {
+    const void* x; /* (batch, h, w, c1) fp16, pixel pitch x_ld */
+    void* y;       /* (batch, h, w, c2) fp16, pixel pitch y_ld */
+    int batch, h, w;
+    int c1, x_ld, ch, c2, y_ld;
+    int shortcut;
+    float slope;
+    y5_csp_stage cv12, m_cv1, m_cv2, cv3, cv4;
+} y5_csp_desc;
+int y5_csp_f16(const y5_csp_desc* d, y5_stream_t stream);
+
 /* A 1x1 stride-1 convolution whose input is the channel concatenation [nearest-2x-upsampled x | x2], without building
  * the upsampled tensor or the concatenation.
  * Replaces: nn.Upsample(None, 2, 'nearest') -> Concat -> the 1x1 convolutions that read it (models/yolov5s.yaml:30-32 and
@@ -378,6 +409,7 @@ int y5_plan_add_decode_multi(y5_plan* p, const y5_decode_desc* levels, int n_lev
 int y5_plan_add_detect(y5_plan* p, const y5_conv_desc* conv, const y5_decode_desc* d, int variant);
 int y5_plan_add_conv_chain(y5_plan* p, const y5_conv_desc* first, const y5_conv_desc* second, int keep_first, int variant);
 int y5_plan_add_conv_cat2(y5_plan* p, const y5_conv_desc* d, const void* x2, int x2_ld, int cin2);
+int y5_plan_add_csp(y5_plan* p, const y5_csp_desc* d);
 /* Mark the op recorded last.  Y5_PLAN_SIDE: y5_plan_run launches it on a second stream owned by the plan, ordered
  * after everything issued before it on the caller's stream -- for an op whose result is needed only much later (the
  * Detect convs of the finer pyramid levels, which can run beside the rest of the head).  Y5_PLAN_JOIN: the caller's
@@ -409,6 +441,7 @@ int y5_plan_profile(y5_plan* p, void* const* ext, int n_ext, y5_stream_t stream,
 #define Y5_OP_STEM_CONV 14
 #define Y5_OP_STEM_CONV_U8 15
 #define Y5_OP_CONV_CAT2 16
+#define Y5_OP_CSP 17
 int y5_plan_op_info(const y5_plan* p, int i, int* kind, double* flops, double* bytes);
 
 #ifdef __cplusplus

@@ -16,7 +16,7 @@ PLAN_SIDE, PLAN_JOIN = 1, 2
 ACT_NONE, ACT_LEAKY = 0, 1
 F16, BF16 = 0, 1  # y5_conv_desc.dtype / y5_decode_desc.dtype
 OK, EINVAL, EHIP, ENOMEM, EWORKSPACE = 0, -1, -2, -3, -4  # y5_status in include/y5hip.h
-OP_NAMES = {16: 'conv', 14: 'focus_conv', 15: 'focus_conv', 13: 'conv', 12: 'detect', 8: 'focus_conv', 9: 'decode', 10: 'focus_conv', 11: 'normalize', 1: 'conv', 2: 'pack', 3: 'maxpool', 4: 'upsample', 5: 'copy', 6: 'decode', 7: 'maxpool'}
+OP_NAMES = {17: 'conv', 16: 'conv', 14: 'focus_conv', 15: 'focus_conv', 13: 'conv', 12: 'detect', 8: 'focus_conv', 9: 'decode', 10: 'focus_conv', 11: 'normalize', 1: 'conv', 2: 'pack', 3: 'maxpool', 4: 'upsample', 5: 'copy', 6: 'decode', 7: 'maxpool'}
 
 
 class ConvDesc(C.Structure):
@@ -27,6 +27,18 @@ class ConvDesc(C.Structure):
                 ('ksize', C.c_int32), ('stride', C.c_int32), ('pad', C.c_int32),
                 ('kpad', C.c_int32), ('w_rows', C.c_int32), ('act', C.c_int32), ('slope', C.c_float),
                 ('variant', C.c_int32), ('dtype', C.c_int32)]
+
+
+class CspStage(C.Structure):
+    _fields_ = [('w', C.c_void_p), ('bias', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p),
+                ('w_ld', C.c_int32), ('reserved', C.c_int32)]
+
+
+class CspDesc(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('y', C.c_void_p), ('batch', C.c_int32), ('h', C.c_int32), ('w', C.c_int32),
+                ('c1', C.c_int32), ('x_ld', C.c_int32), ('ch', C.c_int32), ('c2', C.c_int32), ('y_ld', C.c_int32),
+                ('shortcut', C.c_int32), ('slope', C.c_float),
+                ('cv12', CspStage), ('m_cv1', CspStage), ('m_cv2', CspStage), ('cv3', CspStage), ('cv4', CspStage)]
 
 
 class DecodeDesc(C.Structure):
@@ -58,6 +70,8 @@ SIGNATURES = {
     'y5_stem_conv_u8': (_i, [C.POINTER(ConvDesc), _s]),
     'y5_normalize_u8_f16': (_i, [C.c_void_p, C.c_void_p, C.c_int64, _s]),
     'y5_conv_num_variants': (_i, []),
+    'y5_csp_f16': (_i, [C.POINTER(CspDesc), _s]),
+    'y5_plan_add_csp': (_i, [_p, C.POINTER(CspDesc)]),
     'y5_conv_num_variants_bf16': (_i, []),
     'y5_pack_image_f16': (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _s]),
     'y5_maxpool_f16': (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _s]),

@@ -152,6 +152,11 @@ extern "C" int y5_conv_cat2_f16(const y5_conv_desc* d, const void* x2, int x2_ld
 
 extern "C" int y5_conv_cat2_num_variants(void) { return y5_conv_cat2_variant_count(); }
 
+extern "C" int y5_csp_f16(const y5_csp_desc* d, y5_stream_t stream) {
+    Y5_REQUIRE(d, "csp: null descriptor");
+    return y5_launch_csp(*d, static_cast<hipStream_t>(stream));
+}
+
 // ------------------------------------------------------------------------------------------
 // launch plan
 // ------------------------------------------------------------------------------------------
@@ -173,6 +178,7 @@ struct Op {
     y5_conv_desc conv{};
     y5_conv_desc conv2{};  // Y5_OP_CONV_CHAIN: the second convolution; i[0] variant, i[1] keep_first
                            // Y5_OP_CONV_CAT2: x = the second source, x_ld its pitch, cin its channels
+    y5_csp_desc csp{};     // Y5_OP_CSP
     y5_decode_desc dec{};
     y5_decode_desc decm[Y5_MAX_LEVELS] = {};  // Y5_OP_DECODE_MULTI: i[0] levels
     // generic pointwise arguments
@@ -253,6 +259,11 @@ bool set_ptr(Op& op, int field, const void* v) {
             else if (field == 3) op.conv2.x = v;
             else return false;
             return true;
+        case Y5_OP_CSP:
+            if (field == 0) op.csp.x = v;
+            else if (field == 1) op.csp.y = nv;
+            else return false;
+            return true;
         case Y5_OP_DETECT:
             if (field == 0) op.conv.x = v;
             else if (field == 1) op.dec.x_out = nv;
@@ -292,6 +303,7 @@ int run_op(const Op& op, hipStream_t s) {
         case Y5_OP_DETECT: return y5_launch_detect(op.conv, op.dec, op.i[0], s);
         case Y5_OP_CONV_CHAIN: return y5_launch_conv_chain(op.conv, op.conv2, op.i[1], op.i[0], s);
         case Y5_OP_CONV_CAT2: return y5_launch_conv_cat2(op.conv, op.conv2.x, op.conv2.x_ld, op.conv2.cin, s);
+        case Y5_OP_CSP: return y5_launch_csp(op.csp, s);
     }
     return y5_fail(Y5_EINVAL, "plan: unknown op kind %d", op.kind);
 }
@@ -538,6 +550,23 @@ extern "C" int y5_plan_add_conv_chain(y5_plan* p, const y5_conv_desc* first, con
         op.flops = 2.0 * m * first->cout * first->ksize * first->ksize * first->cin + 2.0 * m * second->cout * first->cout;
         op.bytes = 2.0 * ((double)first->batch * first->h * first->w_in * first->cin + m * first->cout * ((first->res ? 1 : 0) + (keep_first ? 1 : 0)) +
                           (double)first->cout * first->ksize * first->ksize * first->cin + m * second->cout + (double)second->cout * first->cout);
+        p->ops.push_back(op);
+        return Y5_OK;
+    });
+}
+
+extern "C" int y5_plan_add_csp(y5_plan* p, const y5_csp_desc* d) {
+    Y5_REQUIRE(p && d, "plan_add_csp: null argument");
+    return guarded([&]() {
+        Op op;
+        op.kind = Y5_OP_CSP;
+        op.csp = *d;
+        note_ptr(p, op, 0, d->x);
+        note_ptr(p, op, 1, d->y);
+        const double m = (double)d->batch * d->h * d->w;
+        const double macs = (double)d->c1 * 2 * d->ch + (double)d->ch * d->ch * 11 + (double)2 * d->ch * d->c2;  // per pixel
+        op.flops = 2.0 * m * macs;
+        op.bytes = 2.0 * (m * d->c1 + m * d->c2 + macs);
         p->ops.push_back(op);
         return Y5_OK;
     });

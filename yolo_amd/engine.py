@@ -777,6 +777,113 @@ class Plan:
         c1, c2, c3 = m.cv1.conv.out_channels, m.cv2.out_channels, m.cv3.out_channels
         if m.bn.num_features != c3 + c2:
             raise Unsupported('CSP BatchNorm width')
+        if self._csp_one_kernel(name, m, x, out):
+            return
+        self._csp_layers(name, m, x, out)
+
+    def _stage(self, weights, segs, bias=None, affine=None, n=None):
+        """y5_csp_stage of one convolution: packed weights + fp32 parameter vectors of n entries."""
+        packed, kpad, _ = self._pack_weight(weights, segs)
+        st = _lib.CspStage()
+        st.w, st.w_ld = packed.data_ptr(), kpad
+        if bias is not None:
+            st.bias = self._f32(bias, n).data_ptr()
+        if affine is not None:
+            st.scale, st.shift = self._f32(affine[0], n).data_ptr(), self._f32(affine[1], n).data_ptr()
+        return st
+
+    def _conv_stage(self, cm, segs):
+        """y5_csp_stage of a models.common.Conv (fused: bias; unfused: folded BatchNorm)."""
+        n = cm.conv.out_channels
+        if cm.bn is None:
+            return self._stage([(cm.conv.weight, n)], segs, bias=cm.conv.bias, n=n)
+        if cm.conv.bias is not None:
+            raise Unsupported('unfused Conv with conv bias')
+        return self._stage([(cm.conv.weight, n)], segs, affine=bn_affine(cm.bn), n=n)
+
+    def _csp_one_kernel(self, name, m, x, out):
+        """The whole block as one kernel (y5_csp_f16) when it has one Bottleneck and the channel plan the kernel is
+        compiled for, and when that measures faster on this shape than the layer-by-layer plan.  True when recorded."""
+        from yolo_amd.models import common
+        if self.bf16 or os.environ.get('Y5_CSP_FUSE', '1') == '0' or len(m.m) != 1 or isinstance(x, Cat2) or self._defer is not None:
+            return False
+        b = m.m[0]
+        ch = m.cv1.conv.out_channels
+        convs = [m.cv1.conv, m.cv2, b.cv1.conv, m.cv3, m.cv4.conv]
+        slopes = {self._slope(a) for a in (m.cv1.act, b.cv1.act, b.cv2.act, m.act, m.cv4.act)}
+        if not (type(b) is common.Bottleneck and len(x.segs) == 1 and len(out.segs) == 1
+                and (x.c_log, ch, out.c_log) == (64, 32, 64) and x.c_pad == 64 and out.c_pad == 64
+                and all(c.out_channels == ch for c in (m.cv2, b.cv1.conv, b.cv2.conv, m.cv3))
+                and all(_conv_geometry(c) == (1, 1) and c.groups == 1 for c in convs)
+                and _conv_geometry(b.cv2.conv) == (3, 1) and b.cv2.conv.groups == 1
+                and x.h % 8 == 0 and x.w % 32 == 0 and len(slopes) == 1 and None not in slopes):
+            return False
+        for c in convs + [b.cv2.conv]:
+            if c.weight.dtype is not self.dtype or c.weight.device != self.device:
+                raise Unsupported("conv weights must have the input's element type and device")
+        scale, shift = bn_affine(m.bn)
+        dev = self.device
+        d = _lib.CspDesc()
+        d.x, d.y, d.batch, d.h, d.w = x.ptr, out.ptr, x.batch, x.h, x.w
+        d.c1, d.x_ld, d.ch, d.c2, d.y_ld = 64, x.ld, ch, 64, out.ld
+        d.shortcut, d.slope = int(bool(b.add)), slopes.pop()
+        one, zero = torch.ones(ch, device=dev), torch.zeros(ch, device=dev)
+        if m.cv1.bn is None:
+            b1, a1 = m.cv1.conv.bias.detach().float(), (one, zero)
+        else:
+            if m.cv1.conv.bias is not None:
+                raise Unsupported('unfused Conv with conv bias')
+            b1, a1 = None, bn_affine(m.cv1.bn)
+        d.cv12 = self._stage([(m.cv1.conv.weight, ch), (m.cv2.weight, ch)], x.segs, bias=None if b1 is None else torch.cat((b1, zero)),
+                             affine=(torch.cat((a1[0], scale[ch:])), torch.cat((a1[1], shift[ch:]))), n=2 * ch)
+        seg = [(ch, ch)]
+        d.m_cv1, d.m_cv2 = self._conv_stage(b.cv1, seg), self._conv_stage(b.cv2, seg)
+        d.cv3 = self._stage([(m.cv3.weight, ch)], seg, affine=(scale[:ch], shift[:ch]), n=ch)
+        d.cv4 = self._conv_stage(m.cv4, seg * 2)
+        stream = _lib.current_stream()
+        key = ('csp1', x.batch, x.h, x.w, x.ld, out.ld, bool(b.add), m.cv1.bn is None)
+        force = os.environ.get('Y5_CSP_FUSE') == 'force'
+        if os.environ.get('Y5_AUTOTUNE', '1') != '0' and key not in _TUNED and not force:
+            # time the kernel against the layer-by-layer plan of the same block, recorded into a scratch plan
+            x.buf.uniform_(-1.0, 1.0)
+            _lib.check(self.lib.y5_csp_f16(C.byref(d), stream))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(8):
+                self.lib.y5_csp_f16(C.byref(d), stream)
+            e1.record()
+            e1.synchronize()
+            one_ms = e0.elapsed_time(e1) / 8
+            real, keep_n, label_n = self.handle, len(self.keep), len(self.labels)
+            scratch = C.c_void_p()
+            _lib.check(self.lib.y5_plan_create(C.byref(scratch)))
+            self.handle = scratch
+            try:
+                self._csp_layers(name, m, x, out)
+                arr = (C.c_void_p * 1)(0)
+                _lib.check(self.lib.y5_plan_run(scratch, arr, 0, stream))
+                e0.record()
+                for _ in range(8):
+                    self.lib.y5_plan_run(scratch, arr, 0, stream)
+                e1.record()
+                e1.synchronize()
+                layers_ms = e0.elapsed_time(e1) / 8
+            finally:
+                self.handle = real
+                torch.cuda.synchronize()
+                self.lib.y5_plan_destroy(scratch)
+                del self.keep[keep_n:]
+                del self.labels[label_n:]
+            _TUNED[key], _TUNED_MS[key] = int(one_ms < layers_ms), min(one_ms, layers_ms)
+        if not force and not _TUNED.get(key, 1):
+            return False
+        _lib.check(self.lib.y5_plan_add_csp(self.handle, C.byref(d)))
+        self.labels.append('%s whole block 64->(32)->64 @%dx%d, one kernel' % (name, x.h, x.w))
+        return True
+
+    def _csp_layers(self, name, m, x, out):
+        """BottleneckCSP layer by layer (see _csp)."""
+        c1, c2, c3 = m.cv1.conv.out_channels, m.cv2.out_channels, m.cv3.out_channels
         scale, shift = bn_affine(m.bn)
         slope = self._slope(m.act)
         fuse = (pad8(c1) == pad8(c3) and len(m.m) > 0 and self._slope(m.cv1.act) == slope and slope is not None
