@@ -115,11 +115,12 @@ int y5_conv_chain_num_variants(void);
  *     out = cv4(act(bn(cat(y1, y2))))
  * Each stage carries the post-ops of y5_conv_f16 (bias / scale+shift / LeakyReLU, each rounded to fp16), so the result
  * equals the layer-by-layer evaluation up to the fp32 summation order:
- *     cv12   rows [0, ch) = cv1 with its own BatchNorm or bias; rows [ch, 2 ch) = cv2 with the second half of the concat
- *            BatchNorm;   m_cv1, m_cv2 = the Bottleneck's convolutions (m_cv2 is 3x3, k = (r*3+q)*ch + c);
- *     cv3    with the first half of the concat BatchNorm;   cv4 reads [y1 | y2].
+ *     cv1 with its own BatchNorm or bias;   cv2 with the second half of the concat BatchNorm;
+ *     m_cv1, m_cv2 = the Bottleneck's convolutions (m_cv2 is 3x3, k = (r*3+q)*ch + c);
+ *     cv3 with the first half of the concat BatchNorm;   cv4 reads [y1 | y2].
  * Compiled for c1 = 64, ch = 32, c2 = 64 (yolov5s layer 2), h % 8 == 0, w % 32 == 0; Y5_EINVAL otherwise.  Every stage
- * is followed by LeakyReLU(slope). */
+ * is followed by LeakyReLU(slope).  Two post-op patterns are compiled: the Model.fuse()d block (bias only on cv1, m_cv1,
+ * m_cv2, cv4; scale + shift only on cv2, cv3) and the block with live BatchNorms (scale + shift only everywhere). */
 typedef struct y5_csp_stage {
     const void* w;      /* fp16 [rows][w_ld], row n = output channel n, zero padded */
     const float* bias;  /* fp32 per output channel, or NULL */
@@ -135,7 +136,7 @@ typedef struct y5_csp_desc {
     int c1, x_ld, ch, c2, y_ld;
     int shortcut;
     float slope;
-    y5_csp_stage cv12, m_cv1, m_cv2, cv3, cv4;
+    y5_csp_stage cv1, cv2, m_cv1, m_cv2, cv3, cv4;
 } y5_csp_desc;
 int y5_csp_f16(const y5_csp_desc* d, y5_stream_t stream);
 
@@ -165,6 +166,16 @@ int y5_normalize_u8_f16(const void* x_u8, void* y_f16, int64_t n, y5_stream_t st
 /* y5_focus_conv_f16 with that pre-processing folded in: x is the uint8 NCHW image as the data loader delivers it
  * (utils/datasets.py:140-141 after .to(device)); results are bit-identical to normalising first. */
 int y5_focus_conv_u8(const y5_conv_desc* d, y5_stream_t stream);
+/* The same from the decoder's own layout: x is uint8 (batch, h, w_in, 3), channels interleaved, i.e. the image before the
+ * loader's `img[:, :, ::-1].transpose(2, 0, 1)` + np.ascontiguousarray (utils/datasets.py:140-141).  input = Y5_IN_U8_HWC
+ * takes the three bytes of a pixel as the model's channels 0, 1, 2; Y5_IN_U8_HWC_BGR reverses them (the `::-1`: OpenCV's
+ * B, G, R become R, G, B).  Swap, transpose and the division by 255 happen in the kernel's fetch; results are bit-identical
+ * to running the loader's statements first. */
+#define Y5_IN_F16 0
+#define Y5_IN_U8 1
+#define Y5_IN_U8_HWC 2
+#define Y5_IN_U8_HWC_BGR 3
+int y5_focus_conv_u8_hwc(const y5_conv_desc* d, int input, y5_stream_t stream);
 
 /* A first-layer 3x3 stride-1 pad-1 convolution straight from the 3-channel NCHW image, for the graphs that open with a
  * plain Conv instead of Focus (models/yolov5s_ori.yaml layer 0; Conv.forward models/common.py:26 on the loader's image).
@@ -410,6 +421,7 @@ int y5_plan_add_detect(y5_plan* p, const y5_conv_desc* conv, const y5_decode_des
 int y5_plan_add_conv_chain(y5_plan* p, const y5_conv_desc* first, const y5_conv_desc* second, int keep_first, int variant);
 int y5_plan_add_conv_cat2(y5_plan* p, const y5_conv_desc* d, const void* x2, int x2_ld, int cin2);
 int y5_plan_add_csp(y5_plan* p, const y5_csp_desc* d);
+int y5_plan_add_focus_conv_u8_hwc(y5_plan* p, const y5_conv_desc* d, int input);
 /* Mark the op recorded last.  Y5_PLAN_SIDE: y5_plan_run launches it on a second stream owned by the plan, ordered
  * after everything issued before it on the caller's stream -- for an op whose result is needed only much later (the
  * Detect convs of the finer pyramid levels, which can run beside the rest of the head).  Y5_PLAN_JOIN: the caller's
@@ -442,6 +454,7 @@ int y5_plan_profile(y5_plan* p, void* const* ext, int n_ext, y5_stream_t stream,
 #define Y5_OP_STEM_CONV_U8 15
 #define Y5_OP_CONV_CAT2 16
 #define Y5_OP_CSP 17
+#define Y5_OP_FOCUS_CONV_HWC 18
 int y5_plan_op_info(const y5_plan* p, int i, int* kind, double* flops, double* bytes);
 
 #ifdef __cplusplus

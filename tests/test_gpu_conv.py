@@ -302,6 +302,42 @@ def test_focus_conv_u8_equals_normalise_then_focus_conv(dev, shape):
     assert torch.equal(outs[0], outs[1]) and float(outs[0].abs().max()) > 0
 
 
+@pytest.mark.parametrize('shape', [(2, 64, 96, 32), (3, 42, 74, 48), (1, 160, 128, 80), (2, 640, 640, 32)], ids=lambda s: 'x'.join(map(str, s)))
+@pytest.mark.parametrize('bgr', [True, False], ids=['bgr', 'rgb'])
+def test_focus_conv_from_interleaved_uint8_equals_the_loaders_statements_first(dev, shape, bgr):
+    """y5_focus_conv_u8_hwc reads (batch, h, w, 3) uint8 frames: bit-identical to `img[:, :, ::-1].transpose(2, 0, 1)` +
+    np.ascontiguousarray (utils/datasets.py:140-141, done here with numpy on the host exactly as the loader does) followed
+    by y5_focus_conv_u8."""
+    import numpy as np
+    lib = _lib.lib()
+    B, H, W, Co = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    frames = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.int32).to(torch.uint8).numpy()
+    loader = np.stack([np.ascontiguousarray((f[:, :, ::-1] if bgr else f).transpose(2, 0, 1)) for f in frames])
+    img_chw, img_hwc = torch.from_numpy(loader).to(dev), torch.from_numpy(frames).to(dev)
+    wp = torch.zeros(128, 192, dtype=torch.float16, device=dev)
+    wp[:Co, :144] = (torch.randn(Co, 144, generator=g) / 10).half().to(dev)
+    wp.view(128, 12, 16)[:, :, 12:] = 0
+    bias = torch.randn(Co, generator=g).to(dev)
+    outs = []
+    for img, hwc in ((img_chw, False), (img_hwc, True)):
+        y = torch.zeros(B, H // 2, W // 2, Co, dtype=torch.float16, device=dev)
+        d = _lib.ConvDesc()
+        d.x, d.w, d.y, d.bias = img.data_ptr(), wp.data_ptr(), y.data_ptr(), bias.data_ptr()
+        d.batch, d.h, d.w_in, d.cin = B, H, W, 3
+        d.ho, d.wo, d.cout, d.y_ld = H // 2, W // 2, Co, Co
+        d.ksize, d.stride, d.pad, d.kpad, d.w_rows = 3, 1, 1, 192, 128
+        d.act, d.slope = _lib.ACT_LEAKY, 0.1
+        if hwc:
+            _lib.check(lib.y5_focus_conv_u8_hwc(C.byref(d), _lib.IN_U8_HWC_BGR if bgr else _lib.IN_U8_HWC, _lib.current_stream()))
+        else:
+            _lib.check(lib.y5_focus_conv_u8(C.byref(d), _lib.current_stream()))
+        outs.append(y)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and float(outs[0].abs().max()) > 0
+    assert lib.y5_focus_conv_u8_hwc(C.byref(d), _lib.IN_U8, _lib.current_stream()) == _lib.EINVAL
+
+
 def test_conv_into_channel_slice_leaves_neighbours_alone(dev):
     """Concat in place: writing a 32-channel result into channels [64, 96) of a 128-channel buffer."""
     lib = _lib.lib()

@@ -96,6 +96,36 @@ def test_uint8_batch_runs_on_the_engine_like_its_normalised_copy(dev):
     agree(z1, zt, 0.80)
 
 
+@pytest.mark.parametrize('cfg', ['yolov5s', 'yolov5s_ori'])
+def test_interleaved_bgr_frames_run_like_the_loaders_tensor(dev, cfg):
+    """preprocess.from_hwc: the (batch, h, w, 3) BGR uint8 frames go to the model as they are; the result equals feeding
+    the tensor the reference's loader builds from them (utils/datasets.py:140-141) - on the engine's fused first kernel
+    for the Focus graphs (one engine call, no copy), through a converted copy for graphs that open with a plain Conv."""
+    import numpy as np
+    from yolo_amd import preprocess
+    model = util.build_model(cfg)
+    util.randomize_bn(model, 4)
+    model = model.eval().half().to(dev)
+    frames = torch.randint(0, 256, (2, 96, 64, 3), generator=torch.Generator().manual_seed(2), dtype=torch.int32).to(torch.uint8).numpy()
+    loader = np.stack([np.ascontiguousarray(f[:, :, ::-1].transpose(2, 0, 1)) for f in frames])
+    z0, xs0 = model(torch.from_numpy(loader).to(dev))
+    n0 = calls(model)
+    x = preprocess.from_hwc(torch.from_numpy(frames).to(dev), bgr=True)
+    assert x.shape == (2, 3, 96, 64) and x.data_ptr() == x.permute(0, 2, 3, 1).data_ptr()
+    z1, xs1 = model(x)
+    assert calls(model) == n0 + 1
+    if cfg == 'yolov5s':
+        assert any('BGR HWC' in l for p in engine.engine_of(model).plans.values() for l in p.labels)
+        assert torch.equal(z0, z1) and all(torch.equal(a, b) for a, b in zip(xs0, xs1))
+    else:  # normalised by torch before the engine sees it: img.half() / 255.0 instead of the kernel's table, same values
+        assert torch.equal(z0, z1)
+    with engine.disabled():
+        zt, _ = model(x)
+    agree(z1, zt, 0.80)
+    zc, _ = model.float().cpu()(preprocess.from_hwc(torch.from_numpy(frames), bgr=True))   # off the GPU: flip + convert + divide
+    agree(z1, zc, 0.0, rel=3e-2)
+
+
 def test_detections_match_oracle_on_engine_output(dev):
     """forward -> non_max_suppression on the GPU; the NMS stage must reproduce the oracle exactly on the very
     predictions the engine produced (kept boxes are bit-identical given identical scores)."""

@@ -31,8 +31,8 @@ def stage(rows, k, bias=True, scale=False):
     return st
 d = _lib.CspDesc()
 d.x, d.y, d.batch, d.h, d.w = x.data_ptr(), y.data_ptr(), B, H, W
-d.c1, d.x_ld, d.ch, d.c2, d.y_ld, d.shortcut, d.slope = 64, 64, 32, 64, 64, 1, 0.1
-d.cv12, d.m_cv1, d.m_cv2, d.cv3, d.cv4 = stage(64, 64, True, True), stage(32, 32), stage(32, 288), stage(32, 32, False, True), stage(64, 64)
+d.c1, d.x_ld, d.ch, d.c2, d.y_ld, d.shortcut, d.slope = 64, 64, 32, 64, 64, 1 | int(os.environ.get('CSP_DIAG', '0')), 0.1
+d.cv1, d.cv2, d.m_cv1, d.m_cv2, d.cv3, d.cv4 = stage(32, 64), stage(32, 64, False, True), stage(32, 32), stage(32, 288), stage(32, 32, False, True), stage(64, 64)
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 lib.y5_csp_f16.argtypes = [C.c_void_p, C.c_void_p]
 lib.y5_last_error.restype = C.c_char_p

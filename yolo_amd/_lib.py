@@ -15,8 +15,9 @@ NMS_NOALLOC_BYTES = (16 << 20) + 4096  # Y5_NMS_NOALLOC_BYTES
 PLAN_SIDE, PLAN_JOIN = 1, 2
 ACT_NONE, ACT_LEAKY = 0, 1
 F16, BF16 = 0, 1  # y5_conv_desc.dtype / y5_decode_desc.dtype
+IN_F16, IN_U8, IN_U8_HWC, IN_U8_HWC_BGR = 0, 1, 2, 3  # input layouts of y5_focus_conv_u8_hwc
 OK, EINVAL, EHIP, ENOMEM, EWORKSPACE = 0, -1, -2, -3, -4  # y5_status in include/y5hip.h
-OP_NAMES = {17: 'conv', 16: 'conv', 14: 'focus_conv', 15: 'focus_conv', 13: 'conv', 12: 'detect', 8: 'focus_conv', 9: 'decode', 10: 'focus_conv', 11: 'normalize', 1: 'conv', 2: 'pack', 3: 'maxpool', 4: 'upsample', 5: 'copy', 6: 'decode', 7: 'maxpool'}
+OP_NAMES = {18: 'focus_conv', 17: 'conv', 16: 'conv', 14: 'focus_conv', 15: 'focus_conv', 13: 'conv', 12: 'detect', 8: 'focus_conv', 9: 'decode', 10: 'focus_conv', 11: 'normalize', 1: 'conv', 2: 'pack', 3: 'maxpool', 4: 'upsample', 5: 'copy', 6: 'decode', 7: 'maxpool'}
 
 
 class ConvDesc(C.Structure):
@@ -38,7 +39,7 @@ class CspDesc(C.Structure):
     _fields_ = [('x', C.c_void_p), ('y', C.c_void_p), ('batch', C.c_int32), ('h', C.c_int32), ('w', C.c_int32),
                 ('c1', C.c_int32), ('x_ld', C.c_int32), ('ch', C.c_int32), ('c2', C.c_int32), ('y_ld', C.c_int32),
                 ('shortcut', C.c_int32), ('slope', C.c_float),
-                ('cv12', CspStage), ('m_cv1', CspStage), ('m_cv2', CspStage), ('cv3', CspStage), ('cv4', CspStage)]
+                ('cv1', CspStage), ('cv2', CspStage), ('m_cv1', CspStage), ('m_cv2', CspStage), ('cv3', CspStage), ('cv4', CspStage)]
 
 
 class DecodeDesc(C.Structure):
@@ -66,6 +67,8 @@ SIGNATURES = {
     'y5_conv_f16': (_i, [C.POINTER(ConvDesc), _s]),
     'y5_focus_conv_f16': (_i, [C.POINTER(ConvDesc), _s]),
     'y5_focus_conv_u8': (_i, [C.POINTER(ConvDesc), _s]),
+    'y5_focus_conv_u8_hwc': (_i, [C.POINTER(ConvDesc), _i, _s]),
+    'y5_plan_add_focus_conv_u8_hwc': (_i, [_p, C.POINTER(ConvDesc), _i]),
     'y5_stem_conv_f16': (_i, [C.POINTER(ConvDesc), _s]),
     'y5_stem_conv_u8': (_i, [C.POINTER(ConvDesc), _s]),
     'y5_normalize_u8_f16': (_i, [C.c_void_p, C.c_void_p, C.c_int64, _s]),

@@ -62,6 +62,12 @@ extern "C" int y5_focus_conv_u8(const y5_conv_desc* d, y5_stream_t stream) {
     Y5_REQUIRE(d, "focus_conv_u8: null descriptor");
     return y5_launch_focus_conv(*d, static_cast<hipStream_t>(stream), true);
 }
+
+extern "C" int y5_focus_conv_u8_hwc(const y5_conv_desc* d, int input, y5_stream_t stream) {
+    Y5_REQUIRE(d, "focus_conv: null descriptor");
+    Y5_REQUIRE(input == Y5_IN_U8_HWC || input == Y5_IN_U8_HWC_BGR, "focus_conv_u8_hwc: input must be Y5_IN_U8_HWC or Y5_IN_U8_HWC_BGR (got %d)", input);
+    return y5_launch_focus_conv(*d, static_cast<hipStream_t>(stream), input);
+}
 extern "C" int y5_normalize_u8_f16(const void* x, void* y, int64_t n, y5_stream_t stream) {
     return y5_launch_normalize_u8(x, y, n, static_cast<hipStream_t>(stream));
 }
@@ -230,6 +236,7 @@ bool set_ptr(Op& op, int field, const void* v) {
         case Y5_OP_CONV:
         case Y5_OP_FOCUS_CONV:
         case Y5_OP_FOCUS_CONV_U8:
+        case Y5_OP_FOCUS_CONV_HWC:
         case Y5_OP_STEM_CONV:
         case Y5_OP_STEM_CONV_U8:
             if (field == 0) op.conv.x = v;
@@ -288,7 +295,8 @@ int run_op(const Op& op, hipStream_t s) {
     switch (op.kind) {
         case Y5_OP_CONV: return y5_launch_conv(op.conv, s);
         case Y5_OP_FOCUS_CONV: return y5_launch_focus_conv(op.conv, s);
-        case Y5_OP_FOCUS_CONV_U8: return y5_launch_focus_conv(op.conv, s, true);
+        case Y5_OP_FOCUS_CONV_U8: return y5_launch_focus_conv(op.conv, s, Y5_IN_U8);
+        case Y5_OP_FOCUS_CONV_HWC: return y5_launch_focus_conv(op.conv, s, op.i[0]);
         case Y5_OP_STEM_CONV: return y5_launch_stem_conv(op.conv, s);
         case Y5_OP_STEM_CONV_U8: return y5_launch_stem_conv(op.conv, s, true);
         case Y5_OP_NORMALIZE_U8: return y5_launch_normalize_u8(op.px, op.py, op.pixels, s);
@@ -380,6 +388,12 @@ extern "C" int y5_plan_add_conv(y5_plan* p, const y5_conv_desc* d) {
 static int add_focus_conv(y5_plan* p, const y5_conv_desc* d, int kind);
 extern "C" int y5_plan_add_focus_conv(y5_plan* p, const y5_conv_desc* d) { return add_focus_conv(p, d, Y5_OP_FOCUS_CONV); }
 extern "C" int y5_plan_add_focus_conv_u8(y5_plan* p, const y5_conv_desc* d) { return add_focus_conv(p, d, Y5_OP_FOCUS_CONV_U8); }
+extern "C" int y5_plan_add_focus_conv_u8_hwc(y5_plan* p, const y5_conv_desc* d, int input) {
+    Y5_REQUIRE(input == Y5_IN_U8_HWC || input == Y5_IN_U8_HWC_BGR, "plan_add_focus_conv_u8_hwc: input must be Y5_IN_U8_HWC or Y5_IN_U8_HWC_BGR (got %d)", input);
+    const int rc = add_focus_conv(p, d, Y5_OP_FOCUS_CONV_HWC);
+    if (rc == Y5_OK) p->ops.back().i[0] = input;
+    return rc;
+}
 extern "C" int y5_plan_add_stem_conv(y5_plan* p, const y5_conv_desc* d) { return add_focus_conv(p, d, Y5_OP_STEM_CONV); }
 extern "C" int y5_plan_add_stem_conv_u8(y5_plan* p, const y5_conv_desc* d) { return add_focus_conv(p, d, Y5_OP_STEM_CONV_U8); }
 
@@ -393,7 +407,7 @@ static int add_focus_conv(y5_plan* p, const y5_conv_desc* d, int kind) {
         note_ptr(p, op, 1, d->y);
         const double m = (double)d->batch * d->ho * d->wo;
         const bool stem = kind == Y5_OP_STEM_CONV || kind == Y5_OP_STEM_CONV_U8;
-        const bool u8 = kind == Y5_OP_FOCUS_CONV_U8 || kind == Y5_OP_STEM_CONV_U8;
+        const bool u8 = kind == Y5_OP_FOCUS_CONV_U8 || kind == Y5_OP_STEM_CONV_U8 || kind == Y5_OP_FOCUS_CONV_HWC;
         const double taps = stem ? 9.0 : 9.0 * 4;  // Focus: 3x3 over the four space-to-depth copies of each channel
         op.flops = 2.0 * m * d->cout * taps * d->cin;
         op.bytes = (u8 ? 1.0 : 2.0) * d->batch * d->h * d->w_in * d->cin + 2.0 * (m * d->cout + (double)d->cout * taps * d->cin);

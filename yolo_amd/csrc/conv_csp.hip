@@ -1,5 +1,5 @@
 // BottleneckCSP with one Bottleneck as ONE kernel (models/common.py:33-62): for an 8 x 32 pixel tile of the output
-//     [t | y2] = post(W12 . x)            1x1, on the tile + a one-pixel halo   (cv1 with its BatchNorm/activation, cv2 with
+//     [t | y2] = post([W1; W2] . x)           1x1, on the tile + a one-pixel halo   (cv1 with its BatchNorm/activation, cv2 with
 //                                                                                the second half of the concat BatchNorm)
 //     u        = post(Wm1 . t)            1x1, tile + halo, zero outside the image (Bottleneck.cv1; the 3x3's zero padding)
 //     v        = post(Wm2 * u) (+ t)      3x3, tile                              (Bottleneck.cv2 and the shortcut)
@@ -36,7 +36,7 @@ struct CspArgs {
     int H, W, x_ld, y_ld, x_bytes;
     int tiles_y, ntiles;
     FastDiv div_tpi, div_ty;
-    CspStage s12, sm1, sm2, s3, s4;
+    CspStage s1, s2, sm1, sm2, s3, s4;
     float slope;
     int shortcut;
 };
@@ -45,17 +45,17 @@ constexpr int TH = 8, TW = 32, HW = TW + 2, HH = TH + 2, HP = HH * HW;  // tile,
 constexpr int NT1 = (HP + 31) / 32;                                     // 32-pixel groups of the halo tile (11)
 constexpr int NWAVE = TH, NTHREADS = 64 * NWAVE;                        // one wave per tile row
 
-// Which post-ops a stage has, as template bits: stage s (0 = cv1|cv2, 1 = m.cv1, 2 = m.cv2, 3 = cv3, 4 = cv4) has a bias
-// when bit 2s is set and a scale + shift when bit 2s+1 is set.
+// Which post-ops a stage has, as template bits: stage s (0 = cv1, 1 = cv2, 2 = m.cv1, 3 = m.cv2, 4 = cv3, 5 = cv4) has a
+// bias when bit 2s is set and a scale + shift when bit 2s+1 is set.
 constexpr int stage_flags(int s, int flags) { return (flags >> (2 * s)) & 3; }
-constexpr int kFlagsFused = 3 | (1 << 2) | (1 << 4) | (2 << 6) | (1 << 8);    // Model.fuse()d: Conv = conv + bias
-constexpr int kFlagsBn = 2 | (2 << 2) | (2 << 4) | (2 << 6) | (2 << 8);       // every conv followed by a BatchNorm
+constexpr int kFlagsFused = 1 | (2 << 2) | (1 << 4) | (1 << 6) | (2 << 8) | (1 << 10);  // Model.fuse()d: Conv = conv + bias
+constexpr int kFlagsBn = 2 | (2 << 2) | (2 << 4) | (2 << 6) | (2 << 8) | (2 << 10);     // every conv followed by a BatchNorm
 
 template <int C1, int CH, int C2>
 struct CspCfg {
-    static_assert(C1 == 64 && CH == 32 && C2 == 64, "compiled for the 64 -> (32) -> 64 block");
+    static_assert(C1 == 64 && CH == 32 && C2 == 64, "compiled for the 64 -> (32) -> 64 block");  // two K-steps per 32 channels: see uoff
     // LDS rows are unpadded; 16-byte slot s of row p is stored at slot s ^ swz(p), which spreads the 8 rows a ds_read_b128
-    // serves together over all banks: input pixels are 128 bytes (8 slots, swz = p & 7), pixels of t / u / v / y1 / y2
+    // serves together over all banks: input pixels are 128 bytes (8 slots, swz = (p >> 1) & 7), pixels of t / u / v / y1 / y2
     // are 64 bytes (4 slots, swz = (p >> 2) & 3).
     static constexpr int XROW = C1 * 2, TROW = CH * 2;
     static constexpr int X_PIECES = (HP * XROW + 1023) / 1024;   // 1 KiB DMA pieces of one staged input tile (43)
@@ -65,14 +65,14 @@ struct CspCfg {
     static_assert(U_BYTES + V_BYTES <= X_BYTES, "u and v fit the dead input buffer");
     static constexpr int X0 = 0, T0 = 2 * X_BYTES, Y20 = T0 + U_BYTES, PRM0 = Y20 + V_BYTES;
     static constexpr int NPRM = 3 * (2 * CH + CH + CH + CH + C2);
-    static constexpr int W40 = PRM0 + NPRM * 4;   // cv4: row i = channel (i & 32) + perm(i & 31), slot s at s ^ (i & 7)
+    static constexpr int W40 = PRM0 + NPRM * 4;   // cv4: row i = channel (i & 32) + perm(i & 31), slot s at s ^ ((i >> 1) & 7)
     static constexpr int WM2ROW = 9 * CH * 2 + 16;  // m.cv2: row i = channel perm(i), padded to an odd number of slots
     static constexpr int WM20 = W40 + C2 * 2 * CH * 2;
     static constexpr int SMEM = WM20 + CH * WM2ROW;
     static_assert(2 * CH * 2 == 128 && W40 % 16 == 0 && WM20 % 16 == 0, "16-byte aligned weight blocks");
     static_assert(SMEM <= 160 * 1024, "fits the CU's LDS");
     // parameter blocks [bias | scale | shift] per stage, in floats from PRM0
-    static constexpr int P12 = 0, PM1 = P12 + 3 * 2 * CH, PM2 = PM1 + 3 * CH, P3 = PM2 + 3 * CH, P4 = P3 + 3 * CH;
+    static constexpr int P1 = 0, P2 = P1 + 3 * CH, PM1 = P2 + 3 * CH, PM2 = PM1 + 3 * CH, P3 = PM2 + 3 * CH, P4 = P3 + 3 * CH;
 };
 
 // MFMA row i of a 32-row weight fragment holds output channel perm(i): lane (lr, lh) then owns channels [16*lh, 16*lh + 16)
@@ -111,23 +111,37 @@ __device__ __forceinline__ unsigned mix_fma2(unsigned h, float s0, float s1, flo
     return t;
 }
 
-// The 16 channels a lane owns of one accumulator tile after the layer's post-ops, rounded exactly as y5_conv_f16 rounds
-// them: fp16(acc + bias), fp16(that * scale + shift), LeakyReLU as max(h, fp16(h * slope)).  Parameters of channels
-// nl..nl+15 of a stage with n channels.
+// Post-op parameters of the 16 channels nl..nl+15 a lane owns, of a stage with n channels (LDS -> registers).
 template <int F>
-__device__ __forceinline__ void finish(const f32x16& acc, const float* prm, int n, int nl, float slope, float negzero, f16x8& lo, f16x8& hi) {
+struct Prm16 {
+    f32x4 b[(F & 1) ? 4 : 1], sc[(F & 2) ? 4 : 1], sh[(F & 2) ? 4 : 1];
+    __device__ __forceinline__ void load(const float* prm, int n, int nl) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if constexpr (F & 1) b[g] = *reinterpret_cast<const f32x4*>(prm + nl + 4 * g);
+            if constexpr (F & 2) {
+                sc[g] = *reinterpret_cast<const f32x4*>(prm + n + nl + 4 * g);
+                sh[g] = *reinterpret_cast<const f32x4*>(prm + 2 * n + nl + 4 * g);
+            }
+        }
+    }
+};
+
+// The 16 channels a lane owns of one accumulator tile after the layer's post-ops, rounded exactly as y5_conv_f16 rounds
+// them: fp16(acc + bias), fp16(that * scale + shift), LeakyReLU as max(h, fp16(h * slope)).
+template <int F>
+__device__ __forceinline__ void finish(const f32x16& acc, const Prm16<F>& q, float slope, float negzero, f16x8& lo, f16x8& hi) {
     unsigned o[8];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-        if constexpr (F & 1) v += *reinterpret_cast<const f32x4*>(prm + nl + 4 * g);
+        if constexpr (F & 1) v += q.b[g];
         const f16x4 c = __builtin_convertvector(v, f16x4);
         unsigned c0 = __builtin_bit_cast(unsigned, __builtin_shufflevector(c, c, 0, 1));
         unsigned c1 = __builtin_bit_cast(unsigned, __builtin_shufflevector(c, c, 2, 3));
         if constexpr (F & 2) {
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(prm + n + nl + 4 * g), sh = *reinterpret_cast<const f32x4*>(prm + 2 * n + nl + 4 * g);
-            c0 = mix_fma2(c0, sc[0], sc[1], sh[0], sh[1]);
-            c1 = mix_fma2(c1, sc[2], sc[3], sh[2], sh[3]);
+            c0 = mix_fma2(c0, q.sc[g][0], q.sc[g][1], q.sh[g][0], q.sh[g][1]);
+            c1 = mix_fma2(c1, q.sc[g][2], q.sc[g][3], q.sh[g][2], q.sh[g][3]);
         }
         const unsigned t0 = mix_mul2(c0, slope, negzero), t1 = mix_mul2(c1, slope, negzero);
         o[2 * g] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(f16x2, c0), __builtin_bit_cast(f16x2, t0)));
@@ -136,6 +150,12 @@ __device__ __forceinline__ void finish(const f32x16& acc, const float* prm, int 
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     lo = __builtin_bit_cast(f16x8, (u32x4){o[0], o[1], o[2], o[3]});
     hi = __builtin_bit_cast(f16x8, (u32x4){o[4], o[5], o[6], o[7]});
+}
+template <int F>
+__device__ __forceinline__ void finish(const f32x16& acc, const float* prm, int n, int nl, float slope, float negzero, f16x8& lo, f16x8& hi) {
+    Prm16<F> q;
+    q.load(prm, n, nl);
+    finish<F>(acc, q, slope, negzero, lo, hi);
 }
 
 __device__ __forceinline__ f32x16 zero16() {
@@ -167,7 +187,8 @@ __global__ __launch_bounds__(NTHREADS) void csp1_kernel(const CspArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
 
     float* prm = reinterpret_cast<float*>(smem + Cfg::PRM0);
-    stage_params(prm + Cfg::P12, a.s12, 2 * CH, t);
+    stage_params(prm + Cfg::P1, a.s1, CH, t);
+    stage_params(prm + Cfg::P2, a.s2, CH, t);
     stage_params(prm + Cfg::PM1, a.sm1, CH, t);
     stage_params(prm + Cfg::PM2, a.sm2, CH, t);
     stage_params(prm + Cfg::P3, a.s3, CH, t);
@@ -179,14 +200,14 @@ __global__ __launch_bounds__(NTHREADS) void csp1_kernel(const CspArgs a) {
     const int mt1 = wave & 1;
     f16x8 w12[K1], wm1[KH], w3[KH];
 #pragma unroll
-    for (int ks = 0; ks < K1; ++ks) w12[ks] = load_wfrag(a.s12, mt1 * 32, ks * 16, lr, lh);
+    for (int ks = 0; ks < K1; ++ks) w12[ks] = load_wfrag(mt1 ? a.s2 : a.s1, 0, ks * 16, lr, lh);
 #pragma unroll
     for (int ks = 0; ks < KH; ++ks) wm1[ks] = load_wfrag(a.sm1, 0, ks * 16, lr, lh);
 #pragma unroll
     for (int ks = 0; ks < KH; ++ks) w3[ks] = load_wfrag(a.s3, 0, ks * 16, lr, lh);
     for (int i = t; i < C2 * 8; i += NTHREADS) {
         const int row = i >> 3, sl = i & 7;
-        *reinterpret_cast<f16x8*>(smem + Cfg::W40 + row * 128 + ((sl ^ (row & 7)) << 4)) =
+        *reinterpret_cast<f16x8*>(smem + Cfg::W40 + row * 128 + ((sl ^ ((row >> 1) & 7)) << 4)) =
             *reinterpret_cast<const f16x8*>(a.s4.w + (size_t)((row & 32) + perm_row(row & 31)) * a.s4.w_ld + sl * 8);
     }
     for (int i = t; i < CH * (9 * CH / 8); i += NTHREADS) {
@@ -196,15 +217,20 @@ __global__ __launch_bounds__(NTHREADS) void csp1_kernel(const CspArgs a) {
     }
     const unsigned char* w4p = smem + Cfg::W40 + lr * 128;
     const unsigned char* wm2p = smem + Cfg::WM20 + lr * Cfg::WM2ROW + lh * 16;
+    int uoff[9];  // byte offset in u of this lane's K-step-0 fragment per tap (K-step 1 is the slot two further: offset ^ 32)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) uoff[tap] = trow_off((wave + tap / 3) * HW + lr + tap % 3, lh);
 
     // ---- the wave's share of the input copy: piece d = wave + 8j is 1 KiB of the staged tile, 16-byte slot d*64 + lane
-    unsigned rc[DMA_PER_WAVE];  // halo row | halo column << 8 | logical slot of the pixel << 16 | nothing to copy << 20
+    unsigned rc[DMA_PER_WAVE];  // halo row | halo column << 8 | nothing to copy << 20
+    int rel[DMA_PER_WAVE];      // byte offset of the lane's 16 bytes from the halo tile's first pixel
 #pragma unroll
     for (int j = 0; j < DMA_PER_WAVE; ++j) {
         const unsigned slot = (unsigned)((wave + NWAVE * j) * 64 + lane);
-        const unsigned px = slot >> 3, sl = (slot & 7u) ^ (px & 7u);
+        const unsigned px = slot >> 3, sl = (slot & 7u) ^ ((px >> 1) & 7u);
         const unsigned r = px / HW, c = px - r * HW;
-        rc[j] = r | (c << 8) | (sl << 16) | (px >= (unsigned)HP ? 1u << 20 : 0u);
+        rc[j] = r | (c << 8) | (px >= (unsigned)HP ? 1u << 20 : 0u);
+        rel[j] = (int)((r * (unsigned)a.W + c) * (unsigned)(a.x_ld * 2) + sl * 16u);
     }
     const i32x4 xr = make_buf(a.x, a.x_bytes);
 
@@ -222,13 +248,16 @@ __global__ __launch_bounds__(NTHREADS) void csp1_kernel(const CspArgs a) {
     auto issue = [&](int tile, int buf) {
         locate(tile);
         const int base = ((tb * a.H + ty0 - 1) * a.W + tx0 - 1) * (a.x_ld * 2);
+        const bool inner = ty0 > 0 && ty0 + TH < a.H && tx0 > 0 && tx0 + TW < a.W;  // the halo stays inside the image
 #pragma unroll
         for (int j = 0; j < DMA_PER_WAVE; ++j) {
             if (wave + NWAVE * j >= Cfg::X_PIECES) break;  // wave-uniform
-            const int r = (int)(rc[j] & 255u), c = (int)((rc[j] >> 8) & 255u);
-            const bool ok = !(rc[j] >> 20) && (unsigned)(ty0 - 1 + r) < (unsigned)a.H && (unsigned)(tx0 - 1 + c) < (unsigned)a.W;
-            const unsigned vo = ok ? (unsigned)(base + (r * a.W + c) * (a.x_ld * 2) + (int)((rc[j] >> 16) & 15u) * 16) : Y5_BUF_OOB;
-            dma16_buf(xr, vo, (unsigned)(buf * X_BYTES + (wave + NWAVE * j) * 1024));
+            bool ok = !(rc[j] >> 20);
+            if (!inner) {
+                const int r = (int)(rc[j] & 255u), c = (int)((rc[j] >> 8) & 255u);
+                ok = ok && (unsigned)(ty0 - 1 + r) < (unsigned)a.H && (unsigned)(tx0 - 1 + c) < (unsigned)a.W;
+            }
+            dma16_buf(xr, ok ? (unsigned)(base + rel[j]) : Y5_BUF_OOB, (unsigned)(buf * X_BYTES + (wave + NWAVE * j) * 1024));
         }
     };
 
@@ -245,6 +274,9 @@ __global__ __launch_bounds__(NTHREADS) void csp1_kernel(const CspArgs a) {
         else
             asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         CSP_STAMP(0)
+#ifdef Y5_STAMPS
+        if (!(a.shortcut & 4))  // diagnostic: no copies behind the first
+#endif
         if (tile + 1 < last) issue(tile + 1, cur ^ 1);
         locate(tile);
         CSP_STAMP(1)
@@ -255,6 +287,9 @@ __global__ __launch_bounds__(NTHREADS) void csp1_kernel(const CspArgs a) {
         unsigned char* V = X + Cfg::U_BYTES;
 
         // ---- [t | y2] on the halo tile: 2 * NT1 units of 32 pixels x 32 channels
+        Prm16<stage_flags(0, FLAGS)> q1;
+        Prm16<stage_flags(1, FLAGS)> q2;
+        if (mt1 == 0) q1.load(prm + Cfg::P1, CH, 16 * lh); else q2.load(prm + Cfg::P2, CH, 16 * lh);
 #pragma unroll
         for (int i = 0; i < (2 * NT1 + NWAVE - 1) / NWAVE; ++i) {
             const int u = wave + NWAVE * i;
@@ -264,13 +299,14 @@ __global__ __launch_bounds__(NTHREADS) void csp1_kernel(const CspArgs a) {
             f32x16 acc = zero16();
 #pragma unroll
             for (int ks = 0; ks < K1; ++ks)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w12[ks], *reinterpret_cast<const f16x8*>(bp + (((2 * ks + lh) ^ (px & 7)) << 4)), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w12[ks], *reinterpret_cast<const f16x8*>(bp + (((2 * ks + lh) ^ ((px >> 1) & 7)) << 4)), acc, 0, 0, 0);
             f16x8 lo, hi;
-            finish<stage_flags(0, FLAGS)>(acc, prm + Cfg::P12, 2 * CH, mt1 * 32 + 16 * lh, a.slope, negzero, lo, hi);
             if (mt1 == 0) {
+                finish(acc, q1, a.slope, negzero, lo, hi);
                 *reinterpret_cast<f16x8*>(T + trow_off(px, 2 * lh)) = lo;
                 *reinterpret_cast<f16x8*>(T + trow_off(px, 2 * lh + 1)) = hi;
             } else {
+                finish(acc, q2, a.slope, negzero, lo, hi);
                 const int r = px / HW, c = px - r * HW;
                 if (r >= 1 && r <= TH && c >= 1 && c <= TW) {
                     const int q = (r - 1) * TW + c - 1;
@@ -286,7 +322,7 @@ __global__ __launch_bounds__(NTHREADS) void csp1_kernel(const CspArgs a) {
         // ---- u on the halo tile (zero where the halo leaves the image: the 3x3 convolution's padding)
 #pragma unroll
         for (int i = 0; i < (NT1 + NWAVE - 1) / NWAVE; ++i) {
-            const int nt = wave + NWAVE * i;
+            const int nt = (NWAVE - 1 - wave) + NWAVE * i;  // the waves with one stage-1 unit less take two here
             if (nt >= NT1) break;
             const int px = nt * 32 + lr;
             f32x16 acc = zero16();
@@ -294,7 +330,7 @@ __global__ __launch_bounds__(NTHREADS) void csp1_kernel(const CspArgs a) {
             for (int ks = 0; ks < KH; ++ks)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wm1[ks], *reinterpret_cast<const f16x8*>(T + trow_off(px, 2 * ks + lh)), acc, 0, 0, 0);
             f16x8 lo, hi;
-            finish<stage_flags(1, FLAGS)>(acc, prm + Cfg::PM1, CH, 16 * lh, a.slope, negzero, lo, hi);
+            finish<stage_flags(2, FLAGS)>(acc, prm + Cfg::PM1, CH, 16 * lh, a.slope, negzero, lo, hi);
             const int r = px / HW, c = px - r * HW;
             if (!((unsigned)(ty0 - 1 + r) < (unsigned)a.H && (unsigned)(tx0 - 1 + c) < (unsigned)a.W)) {
 #pragma unroll
@@ -312,15 +348,14 @@ __global__ __launch_bounds__(NTHREADS) void csp1_kernel(const CspArgs a) {
             f32x16 acc = zero16();
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
-                const int p = (wave + tap / 3) * HW + lr + tap % 3;
 #pragma unroll
                 for (int ks = 0; ks < KH; ++ks)
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(wm2p + (tap * KH + ks) * 32),
-                                                                 *reinterpret_cast<const f16x8*>(U + trow_off(p, 2 * ks + lh)), acc, 0, 0, 0);
+                                                                 *reinterpret_cast<const f16x8*>(U + (uoff[tap] ^ (ks << 5))), acc, 0, 0, 0);
             }
             f16x8 lo, hi;
-            finish<stage_flags(2, FLAGS)>(acc, prm + Cfg::PM2, CH, 16 * lh, a.slope, negzero, lo, hi);
-            if (a.shortcut) {
+            finish<stage_flags(3, FLAGS)>(acc, prm + Cfg::PM2, CH, 16 * lh, a.slope, negzero, lo, hi);
+            if (a.shortcut & 1) {
                 const int p = (wave + 1) * HW + lr + 1;
                 lo += *reinterpret_cast<const f16x8*>(T + trow_off(p, 2 * lh));
                 hi += *reinterpret_cast<const f16x8*>(T + trow_off(p, 2 * lh + 1));
@@ -333,7 +368,7 @@ __global__ __launch_bounds__(NTHREADS) void csp1_kernel(const CspArgs a) {
 #pragma unroll
             for (int ks = 0; ks < KH; ++ks)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3[ks], *reinterpret_cast<const f16x8*>(V + trow_off(q, 2 * ks + lh)), acc, 0, 0, 0);
-            finish<stage_flags(3, FLAGS)>(acc, prm + Cfg::P3, CH, 16 * lh, a.slope, negzero, lo, hi);
+            finish<stage_flags(4, FLAGS)>(acc, prm + Cfg::P3, CH, 16 * lh, a.slope, negzero, lo, hi);
             *reinterpret_cast<f16x8*>(V + trow_off(q, 2 * lh)) = lo;  // y1 over v: the same wave read these rows just above
             *reinterpret_cast<f16x8*>(V + trow_off(q, 2 * lh + 1)) = hi;
 
@@ -341,15 +376,18 @@ __global__ __launch_bounds__(NTHREADS) void csp1_kernel(const CspArgs a) {
 #pragma unroll
             for (int ks = 0; ks < 2 * KH; ++ks) {
                 const f16x8 xf = *reinterpret_cast<const f16x8*>((ks < KH ? V : Y2) + trow_off(q, 2 * (ks % KH) + lh));
-                const int so = ((2 * ks + lh) ^ (lr & 7)) << 4;
+                const int so = ((2 * ks + lh) ^ ((lr >> 1) & 7)) << 4;
                 o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(w4p + so), xf, o0, 0, 0, 0);
                 o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(w4p + 32 * 128 + so), xf, o1, 0, 0, 0);
             }
             f16* yp = a.y + ((size_t)(tb * a.H + ty0 + wave) * a.W + tx0 + lr) * a.y_ld + 16 * lh;
-            finish<stage_flags(4, FLAGS)>(o0, prm + Cfg::P4, C2, 16 * lh, a.slope, negzero, lo, hi);
+#ifdef Y5_STAMPS
+            if (a.shortcut & 2) yp = a.y + (size_t)(blockIdx.x * NWAVE + wave) * 4096 + lane * 64;  // diagnostic: every store of a wave to one place
+#endif
+            finish<stage_flags(5, FLAGS)>(o0, prm + Cfg::P4, C2, 16 * lh, a.slope, negzero, lo, hi);
             *reinterpret_cast<f16x8*>(yp) = lo;
             *reinterpret_cast<f16x8*>(yp + 8) = hi;
-            finish<stage_flags(4, FLAGS)>(o1, prm + Cfg::P4, C2, 32 + 16 * lh, a.slope, negzero, lo, hi);
+            finish<stage_flags(5, FLAGS)>(o1, prm + Cfg::P4, C2, 32 + 16 * lh, a.slope, negzero, lo, hi);
             *reinterpret_cast<f16x8*>(yp + 32) = lo;
             *reinterpret_cast<f16x8*>(yp + 40) = hi;
         }
@@ -395,9 +433,9 @@ int y5_launch_csp(const y5_csp_desc& d, hipStream_t s) {
     Y5_REQUIRE(d.x_ld >= d.c1 && d.y_ld >= d.c2 && d.x_ld % 8 == 0 && d.y_ld % 8 == 0 && y5_aligned16(d.x) && y5_aligned16(d.y),
                "csp: tensors must be 16-byte aligned with pitches that are multiples of 8 channels");
     Y5_REQUIRE(d.slope > 0.f && d.slope <= 1.f, "csp: LeakyReLU slope %g outside (0, 1]", (double)d.slope);
-    const y5_csp_stage* st[5] = {&d.cv12, &d.m_cv1, &d.m_cv2, &d.cv3, &d.cv4};
-    const int kmin[5] = {d.c1, d.ch, 9 * d.ch, d.ch, 2 * d.ch};
-    for (int i = 0; i < 5; ++i) {
+    const y5_csp_stage* st[6] = {&d.cv1, &d.cv2, &d.m_cv1, &d.m_cv2, &d.cv3, &d.cv4};
+    const int kmin[6] = {d.c1, d.c1, d.ch, 9 * d.ch, d.ch, 2 * d.ch};
+    for (int i = 0; i < 6; ++i) {
         Y5_REQUIRE(st[i]->w && y5_aligned16(st[i]->w) && st[i]->w_ld >= kmin[i] && st[i]->w_ld % 8 == 0, "csp: stage %d weights missing, unaligned or too narrow", i);
         Y5_REQUIRE(!st[i]->scale || st[i]->shift, "csp: stage %d has a scale but no shift", i);
     }
@@ -414,12 +452,12 @@ int y5_launch_csp(const y5_csp_desc& d, hipStream_t s) {
     a.ntiles = (int)total;
     a.div_tpi = make_fastdiv((unsigned)(a.tiles_y * tiles_x));
     a.div_ty = make_fastdiv((unsigned)a.tiles_y);
-    a.s12 = make_stage(d.cv12); a.sm1 = make_stage(d.m_cv1); a.sm2 = make_stage(d.m_cv2); a.s3 = make_stage(d.cv3); a.s4 = make_stage(d.cv4);
+    a.s1 = make_stage(d.cv1); a.s2 = make_stage(d.cv2); a.sm1 = make_stage(d.m_cv1); a.sm2 = make_stage(d.m_cv2); a.s3 = make_stage(d.cv3); a.s4 = make_stage(d.cv4);
     a.slope = d.slope;
     a.shortcut = d.shortcut;
     typedef CspCfg<64, 32, 64> Cfg;
     int flags = 0;
-    for (int i = 0; i < 5; ++i) flags |= ((st[i]->bias ? 1 : 0) | (st[i]->scale ? 2 : 0)) << (2 * i);
+    for (int i = 0; i < 6; ++i) flags |= ((st[i]->bias ? 1 : 0) | (st[i]->scale ? 2 : 0)) << (2 * i);
     void (*kernel)(const CspArgs) = flags == kFlagsFused ? csp1_kernel<64, 32, 64, kFlagsFused> : flags == kFlagsBn ? csp1_kernel<64, 32, 64, kFlagsBn> : nullptr;
     Y5_REQUIRE(kernel, "csp: compiled for bias-only Convs (fused model) or scale+shift-only Convs (BatchNorm), got post-op pattern 0x%x", flags);
     static std::atomic<unsigned long long> attr_set[2];

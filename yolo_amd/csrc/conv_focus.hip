@@ -14,7 +14,8 @@
 namespace {
 
 struct FocusArgs {
-    const void* img;  // [B][3][H][W], fp16 or (U8 kernels) uint8 to be divided by 255
+    const void* img;  // [B][3][H][W] fp16, or uint8 to be divided by 255: [B][3][H][W], or [B][H][W][3] (IN == 2)
+    int bgr;          // IN == 2: the three interleaved bytes of a pixel are B, G, R (the model's channel c is byte 2 - c)
     const f16* w;     // packed rows, k = (r*3 + q)*16 + (dy + 2*dx)*3 + c
     const float *bias, *scale, *shift;
     f16* y;
@@ -69,8 +70,12 @@ __device__ __forceinline__ void finish_tile(const f32x16 (&acc)[2][RN], const Fo
 
 // U8: the image is uint8 and the kernel applies the reference's pre-processing img.half() / 255.0 (test.py:152-154) on
 // the way in, through a 256-entry table of fp16(float(v) / 255.0f) -- the input then costs a quarter of the fp16 bytes.
-template <int RN, bool U8>
+// IN == 2: uint8 in the decoder's own layout, [B][H][W][3] (what cv2.imread / the reference's letterbox produce before
+// `img[:, :, ::-1].transpose(2, 0, 1)`, utils/datasets.py:140): the BGR -> RGB swap and the HWC -> CHW transpose happen in
+// the fetch (two byte loads per channel and pixel pair instead of one 16-bit load), nothing is copied beforehand.
+template <int RN, int IN>
 __global__ __launch_bounds__(256) void focus_conv_kernel(const FocusArgs a) {
+    constexpr bool U8 = IN != 0, HWC = IN == 2;
     constexpr int CN = RN * 32;                    // channels held by the workgroup
     constexpr int EROW = CN * 2 + 16;              // bytes per pixel in a wave's output scratch
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -109,32 +114,38 @@ __global__ __launch_bounds__(256) void focus_conv_kernel(const FocusArgs a) {
     // registers one tile ahead) are stored to the other, and the fetch after next is issued before the epilogue.
     const int r7 = t / kPatchDw, dwc = t - r7 * kPatchDw;
     const bool stager = t < kSlabRows * kPatchDw;
-    const unsigned voff = (unsigned)(r7 * a.W + 2 * dwc) * (U8 ? 1u : 2u);  // bytes from a slab's first element
+    const unsigned voff = (unsigned)(r7 * a.W + 2 * dwc) * (HWC ? 3u : U8 ? 1u : 2u);  // bytes from a slab's first element
     uint32_t pre[kSlabs];
     auto fetch = [&](int tile) {
         const int b = tile / tiles_per_img, rem = tile - b * tiles_per_img;
         const int iy0 = 2 * ((rem / a.tiles_x) * 8) - 2, ix0 = 2 * ((rem % a.tiles_x) * 32) - 2;
         constexpr int ESZ = U8 ? 1 : 2;  // bytes per image element
         const unsigned char* origin =
-            static_cast<const unsigned char*>(a.img) + ((ptrdiff_t)b * 3 * a.H * a.W + (ptrdiff_t)iy0 * a.W + ix0) * ESZ;
+            HWC ? static_cast<const unsigned char*>(a.img) + (((ptrdiff_t)b * a.H + iy0) * a.W + ix0) * 3
+                : static_cast<const unsigned char*>(a.img) + ((ptrdiff_t)b * 3 * a.H * a.W + (ptrdiff_t)iy0 * a.W + ix0) * ESZ;
+        // first element of slab i (channel i / 3, rows 7 * (i % 3) ...): wave-uniform
+        auto slab_of = [&](int i) {
+            if constexpr (HWC) return origin + (size_t)(kSlabRows * (i % 3)) * a.W * 3 + (a.bgr ? 2 - i / 3 : i / 3);
+            else return origin + ((size_t)(i / 3) * a.H + kSlabRows * (i % 3)) * a.W * ESZ;
+        };
+        auto load2 = [&](const unsigned char* p) -> uint32_t {  // two neighbouring pixels of one channel
+            if constexpr (HWC) return (uint32_t)p[0] | (uint32_t)p[3] << 8;
+            else if constexpr (U8) return *reinterpret_cast<const unsigned short*>(p);
+            else return *reinterpret_cast<const uint32_t*>(p);
+        };
         const bool interior = iy0 >= 0 && iy0 + kPatchRows <= a.H && ix0 >= 0 && ix0 + 2 * kPatchDw <= a.W;
         if (!stager) return;
         if (interior) {
 #pragma unroll
-            for (int i = 0; i < kSlabs; ++i) {
-                const unsigned char* slab = origin + ((size_t)(i / 3) * a.H + kSlabRows * (i % 3)) * a.W * ESZ;  // wave-uniform
-                pre[i] = U8 ? *reinterpret_cast<const unsigned short*>(slab + voff) : *reinterpret_cast<const uint32_t*>(slab + voff);
-            }
+            for (int i = 0; i < kSlabs; ++i) pre[i] = load2(slab_of(i) + voff);
         } else {
             const int ix = ix0 + 2 * dwc;
             const bool xok = ix >= 0 && ix < a.W;
 #pragma unroll
             for (int i = 0; i < kSlabs; ++i) {
-                const unsigned char* slab = origin + ((size_t)(i / 3) * a.H + kSlabRows * (i % 3)) * a.W * ESZ;
                 const int iy = iy0 + kSlabRows * (i % 3) + r7;
                 const bool ok = xok && iy >= 0 && iy < a.H;
-                const unsigned char* src = ok ? slab + voff : static_cast<const unsigned char*>(a.img);
-                const uint32_t v = U8 ? *reinterpret_cast<const unsigned short*>(src) : *reinterpret_cast<const uint32_t*>(src);
+                const uint32_t v = load2(ok ? slab_of(i) + voff : static_cast<const unsigned char*>(a.img));
                 pre[i] = ok ? v : 0u;  // padding: byte 0 maps to norm[0] = 0.0 as well
             }
         }
@@ -210,19 +221,19 @@ __global__ __launch_bounds__(256) void focus_conv_kernel(const FocusArgs a) {
     }
 }
 
-template <int RN, bool U8>
+template <int RN, int IN>
 int launch_focus(const FocusArgs& a, hipStream_t s) {
     constexpr int CN = RN * 32;
     constexpr size_t lds = (size_t)CN * kWPitch * 2 + 2 * kPatchBuf * 4 + 4 * 32 * (CN * 2 + 16) + 3 * CN * 4 + 256 * 2;
     static std::atomic<unsigned long long> attr_set{0};  // one bit per device: the attribute is per function and device
     const unsigned long long attr_set_bit = 1ull << y5_current_device();
     if (!(attr_set.load() & attr_set_bit)) {
-        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(focus_conv_kernel<RN, U8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(focus_conv_kernel<RN, IN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set.fetch_or(attr_set_bit);
     }
     const int per_cu = RN == 1 ? 4 : RN == 2 ? 3 : 2;
     const int grid = a.ntiles < 256 * per_cu ? a.ntiles : 256 * per_cu;
-    hipLaunchKernelGGL((focus_conv_kernel<RN, U8>), dim3((unsigned)grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((focus_conv_kernel<RN, IN>), dim3((unsigned)grid), dim3(256), lds, s, a);
     Y5_LAUNCH_CHECK("focus_conv_kernel");
     return Y5_OK;
 }
@@ -392,7 +403,9 @@ int launch_stem(const FocusArgs& a, hipStream_t s) {
 
 }  // namespace
 
-int y5_launch_focus_conv(const y5_conv_desc& d, hipStream_t s, bool u8) {
+int y5_launch_focus_conv(const y5_conv_desc& d, hipStream_t s, int input) {
+    const bool u8 = input != Y5_IN_F16;
+    Y5_REQUIRE(input >= Y5_IN_F16 && input <= Y5_IN_U8_HWC_BGR, "focus_conv: unknown input layout %d", input);
     Y5_REQUIRE(d.dtype == Y5_F16, "focus_conv: fp16 only (dtype %d)", d.dtype);
     Y5_REQUIRE(d.x && d.w && d.y, "focus_conv: null image, weight or output pointer");
     Y5_REQUIRE(d.cin == 3, "focus_conv: the image must have 3 channels (got %d)", d.cin);
@@ -406,7 +419,7 @@ int y5_launch_focus_conv(const y5_conv_desc& d, hipStream_t s, bool u8) {
     Y5_REQUIRE(!d.res, "focus_conv: no residual input");
     Y5_REQUIRE((d.scale == nullptr) == (d.shift == nullptr), "focus_conv: scale and shift come together");
     Y5_REQUIRE(d.act == Y5_ACT_NONE || (d.act == Y5_ACT_LEAKY && d.slope > 0.f && d.slope <= 1.f), "focus_conv: bad activation");
-    Y5_REQUIRE((reinterpret_cast<uintptr_t>(d.x) & (u8 ? 1u : 3u)) == 0 && y5_aligned16(d.y) && y5_aligned16(d.w), "focus_conv: misaligned pointer");
+    Y5_REQUIRE((reinterpret_cast<uintptr_t>(d.x) & (input >= Y5_IN_U8_HWC ? 0u : u8 ? 1u : 3u)) == 0 && y5_aligned16(d.y) && y5_aligned16(d.w), "focus_conv: misaligned pointer");
     FocusArgs a{};
     a.img = d.x;
     a.w = static_cast<const f16*>(d.w);
@@ -418,14 +431,20 @@ int y5_launch_focus_conv(const y5_conv_desc& d, hipStream_t s, bool u8) {
     Y5_REQUIRE(nt < (1LL << 31), "focus_conv: too many tiles");
     a.ntiles = (int)nt;
     a.slope = d.act == Y5_ACT_LEAKY ? d.slope : 1.f;
-    if (u8) {
-        if (d.cout <= 32) return launch_focus<1, true>(a, s);
-        if (d.cout <= 64) return launch_focus<2, true>(a, s);
-        return launch_focus<3, true>(a, s);
+    a.bgr = input == Y5_IN_U8_HWC_BGR;
+    if (input >= Y5_IN_U8_HWC) {
+        if (d.cout <= 32) return launch_focus<1, 2>(a, s);
+        if (d.cout <= 64) return launch_focus<2, 2>(a, s);
+        return launch_focus<3, 2>(a, s);
     }
-    if (d.cout <= 32) return launch_focus<1, false>(a, s);
-    if (d.cout <= 64) return launch_focus<2, false>(a, s);
-    return launch_focus<3, false>(a, s);
+    if (u8) {
+        if (d.cout <= 32) return launch_focus<1, 1>(a, s);
+        if (d.cout <= 64) return launch_focus<2, 1>(a, s);
+        return launch_focus<3, 1>(a, s);
+    }
+    if (d.cout <= 32) return launch_focus<1, 0>(a, s);
+    if (d.cout <= 64) return launch_focus<2, 0>(a, s);
+    return launch_focus<3, 0>(a, s);
 }
 
 int y5_launch_stem_conv(const y5_conv_desc& d, hipStream_t s, bool u8) {

@@ -105,7 +105,8 @@ int y5_conv_bf16_variant_count();
 int y5_launch_conv_cat2(const y5_conv_desc& d, const void* x2, int x2_ld, int cin2, hipStream_t s);
 int y5_conv_cat2_variant_count();
 // Focus gather + 3x3 convolution from the NCHW image (conv_focus.hip); d.x is the image, d.cin its 3 channels.
-int y5_launch_focus_conv(const y5_conv_desc& d, hipStream_t s, bool u8 = false);
+// input: Y5_IN_F16 / Y5_IN_U8 (NCHW planes) or Y5_IN_U8_HWC / Y5_IN_U8_HWC_BGR (interleaved bytes)
+int y5_launch_focus_conv(const y5_conv_desc& d, hipStream_t s, int input = Y5_IN_F16);
 int y5_launch_stem_conv(const y5_conv_desc& d, hipStream_t s, bool u8 = false);
 int y5_launch_normalize_u8(const void* x, void* y, long long n, hipStream_t s);
 int y5_launch_pack_image(const void* x, void* y, int batch, int c, int h, int w, int focus, int y_ld, hipStream_t s);

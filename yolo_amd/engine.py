@@ -106,6 +106,16 @@ def _has_hooks(model):
     return False
 
 
+def input_layout(x):
+    """How the image bytes of a 4-d (batch, channel, height, width) input lie in memory: _lib.IN_U8_HWC(_BGR) for a uint8
+    tensor that is a permuted view of a (batch, height, width, 3) array - torch's channels_last - optionally marked as
+    BGR by yolo_amd.preprocess.from_hwc; 0 for everything else (read as, or copied to, contiguous NCHW)."""
+    if (x.dtype is torch.uint8 and x.dim() == 4 and x.shape[1] == 3 and not x.is_contiguous()
+            and x.is_contiguous(memory_format=torch.channels_last)):
+        return _lib.IN_U8_HWC_BGR if getattr(x, 'y5_bgr', False) else _lib.IN_U8_HWC
+    return 0
+
+
 def eligible(model, x):
     """True when this forward may run on the HIP engine: inference mode on a GPU in fp16 or bf16, no autograd,
     no module hooks (the pruning / FLOP-counting tools attach hooks and need the torch modules to run),
@@ -247,6 +257,7 @@ class Plan:
         self.dtype = torch.bfloat16 if x.dtype is torch.bfloat16 else torch.float16
         self.bf16 = self.dtype is torch.bfloat16
         self.batch, self.cin, self.h, self.w = x.shape
+        self.hwc = input_layout(x)  # interleaved uint8 image: only the fused Focus kernel reads it
         self.keep = []          # tensors the plan's device pointers refer to
         self.labels = []        # one human-readable label per op
         self._defer = None      # list collecting (label, descriptor, input) instead of recording, see _emit_conv
@@ -341,13 +352,18 @@ class Plan:
         if image is not None:
             d.batch, d.h, d.w_in, d.cin, d.x_ld = image.shape[0], image.shape[2], image.shape[3], image.shape[1], 0
             u8 = image.dtype is torch.uint8
-            if stem:  # a plain first-layer conv on the image itself (x is the shape-only padded NHWC view of it)
-                add = self.lib.y5_plan_add_stem_conv_u8 if u8 else self.lib.y5_plan_add_stem_conv
+            if self.hwc:
+                if stem:
+                    raise Unsupported('an interleaved uint8 image is read by the fused Focus kernel only')
+                _lib.check(self.lib.y5_plan_add_focus_conv_u8_hwc(self.handle, C.byref(d), self.hwc))
             else:
-                add = self.lib.y5_plan_add_focus_conv_u8 if u8 else self.lib.y5_plan_add_focus_conv
-            _lib.check(add(self.handle, C.byref(d)))
-            self.labels.append('%s %s%sconv3x3 %d->%d @%dx%d' % (label, 'u8/255+' if u8 else '', 'image ' if stem else 'focus+',
-                                                                   x.c_log, out.c_log, ho, wo))
+                if stem:  # a plain first-layer conv on the image itself (x is the shape-only padded NHWC view of it)
+                    add = self.lib.y5_plan_add_stem_conv_u8 if u8 else self.lib.y5_plan_add_stem_conv
+                else:
+                    add = self.lib.y5_plan_add_focus_conv_u8 if u8 else self.lib.y5_plan_add_focus_conv
+                _lib.check(add(self.handle, C.byref(d)))
+            kind = ('u8 %s/255+' % ('BGR HWC' if self.hwc == _lib.IN_U8_HWC_BGR else 'HWC')) if self.hwc else 'u8/255+' if u8 else ''
+            self.labels.append('%s %s%sconv3x3 %d->%d @%dx%d' % (label, kind, 'image ' if stem else 'focus+', x.c_log, out.c_log, ho, wo))
             return
         if cat2 is not None:
             a, b = cat2.a, cat2.b
@@ -500,6 +516,8 @@ class Plan:
 
     def _as_f16(self, image):
         """The NCHW input as fp16: itself, or for a uint8 input a buffer filled by a normalise op (x.half() / 255)."""
+        if self.hwc:
+            raise Unsupported('an interleaved uint8 image is read by the fused Focus kernel only')
         if image.dtype is not torch.uint8:
             return image
         out = torch.zeros(image.shape, dtype=torch.float16, device=self.device)
@@ -827,15 +845,8 @@ class Plan:
         d.x, d.y, d.batch, d.h, d.w = x.ptr, out.ptr, x.batch, x.h, x.w
         d.c1, d.x_ld, d.ch, d.c2, d.y_ld = 64, x.ld, ch, 64, out.ld
         d.shortcut, d.slope = int(bool(b.add)), slopes.pop()
-        one, zero = torch.ones(ch, device=dev), torch.zeros(ch, device=dev)
-        if m.cv1.bn is None:
-            b1, a1 = m.cv1.conv.bias.detach().float(), (one, zero)
-        else:
-            if m.cv1.conv.bias is not None:
-                raise Unsupported('unfused Conv with conv bias')
-            b1, a1 = None, bn_affine(m.cv1.bn)
-        d.cv12 = self._stage([(m.cv1.conv.weight, ch), (m.cv2.weight, ch)], x.segs, bias=None if b1 is None else torch.cat((b1, zero)),
-                             affine=(torch.cat((a1[0], scale[ch:])), torch.cat((a1[1], shift[ch:]))), n=2 * ch)
+        d.cv1 = self._conv_stage(m.cv1, x.segs)
+        d.cv2 = self._stage([(m.cv2.weight, ch)], x.segs, affine=(scale[ch:], shift[ch:]), n=ch)
         seg = [(ch, ch)]
         d.m_cv1, d.m_cv2 = self._conv_stage(b.cv1, seg), self._conv_stage(b.cv2, seg)
         d.cv3 = self._stage([(m.cv3.weight, ch)], seg, affine=(scale[:ch], shift[:ch]), n=ch)
@@ -1181,7 +1192,7 @@ class Engine:
                 p.close()
             self.plans.clear()
             self.signature = sig
-        key = (tuple(x.shape), x.device.index, x.dtype)
+        key = (tuple(x.shape), x.device.index, x.dtype, input_layout(x))
         plan = self.plans.get(key)
         if plan is None:
             if self.unsupported is not None and self.unsupported[0] == (sig, key):
@@ -1211,7 +1222,8 @@ class Engine:
         plan = self._plan(x)
         if plan is None:
             raise _lib.Y5Error('model not supported by the HIP engine: %s' % (self.unsupported or ('', ''))[1])
-        x = x.contiguous()
+        if not plan.hwc:
+            x = x.contiguous()
         with torch.cuda.device(x.device):
             z, xs = plan.run(x)
         self.calls += 1

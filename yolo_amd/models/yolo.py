@@ -114,7 +114,11 @@ class Model(nn.Module):
         if not profile and engine.eligible(self, x):
             return engine.run(self, x)
         if isinstance(x, torch.Tensor) and x.dtype is torch.uint8:  # same convenience off the engine: test.py:152-154
+            if getattr(x, 'y5_bgr', False):  # yolo_amd.preprocess.from_hwc(..., bgr=True): utils/datasets.py:140
+                x = x.flip(1)
             x = x.to(next(self.parameters()).dtype) / 255.0
+            if not profile and engine.eligible(self, x):
+                return engine.run(self, x)
         return self._forward_modules(x, profile)
 
     def _forward_modules(self, x, profile=False):
