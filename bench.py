@@ -254,12 +254,12 @@ def main():
         # which roof binds the convolution work of this model: its FLOP/byte against the machine's
         hbm_bound = conv_bytes / (PEAK_HBM_GBS * 1e9) >= conv_flops / (PEAK_MFMA_TFLOPS * 1e12)
         traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'r1_hbm_traffic.json')
+        tpath = os.path.join(ROOT, 'profiles', 'r2_hbm_traffic.json')  # written by tools/round_profile.sh on this plan
         if os.path.exists(tpath) and args.model == 'yolov5s' and args.batch == 32:
             with open(tpath) as f:
                 traffic = json.load(f).get('conv_total')  # rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of the same launches
         top = sorted(conv, key=lambda a: -a['ms'])[:6]
-        roofline = {'kernel': 'convolution kernels (conv_igemm / conv_lw / conv_ws1x1 / conv3x3_ws / focus_conv): all %d launches of one forward'
+        roofline = {'kernel': 'convolution kernels (conv_igemm / conv_lw / conv_lin3 / conv_ws1x1 / conv3x3_ws / focus_conv / csp1): all %d launches of one forward'
                               % len(conv),
                     'bound': 'hbm' if hbm_bound else 'mfma',
                     'achieved': round(gbs if hbm_bound else tflops, 2), 'peak': PEAK_HBM_GBS if hbm_bound else PEAK_MFMA_TFLOPS,

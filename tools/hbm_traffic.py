@@ -25,7 +25,9 @@ def one_step(root, counter):
 
 
 def family(name):
-    for key in ('focus_conv', 'conv_lw', 'conv_igemm', 'conv_halo', 'conv_ws1x1', 'conv3x3_ws', 'detect_decode', 'nms_', 'maxpool', 'upsample', 'copy_channels'):
+    if 'csp1_kernel' in name:
+        return 'conv_csp'
+    for key in ('focus_conv', 'conv_lw', 'conv_lin3', 'conv_igemm', 'conv_halo', 'conv_ws1x1', 'conv3x3_ws', 'detect_decode', 'nms_', 'maxpool', 'upsample', 'copy_channels'):
         if key in name:
             return key
     return 'other'
