@@ -25,7 +25,7 @@ def _class_mask(classes, nc, device):
 
 
 def nms_padded(prediction, conf_thres=0.1, iou_thres=0.6, classes=None, agnostic=False, max_det=MAX_DET,
-               max_candidates=None, return_index=False, check_overflow=True):
+               max_candidates=None, return_index=False, check_overflow=True, stream=None):
     """Run the batched pipeline on a (B, N, 5+nc) fp16/fp32 GPU tensor.
 
     Returns (det, count) or (det, count, kept_index, n_candidates): det (B, max_det, 6) fp32 rows
@@ -33,6 +33,12 @@ def nms_padded(prediction, conf_thres=0.1, iou_thres=0.6, classes=None, agnostic
     the per-image candidate totals are read back once and the call is repeated with a larger capacity
     when an image produced more candidates than max_candidates; pass check_overflow=False (and inspect
     n_candidates yourself) to stay asynchronous.
+
+    stream: a torch.cuda.Stream to run the pipeline on instead of the current one.  The call is ordered after the work
+    already issued on the current stream (the forward that produced `prediction`) and returns at once; the current
+    stream does NOT wait for it, so a following forward of the next batch runs beside this NMS (its kernels are small
+    and leave most of the chip idle).  The results belong to `stream`: make the consumer wait for it
+    (torch.cuda.current_stream().wait_stream(stream), or stream.synchronize()) before reading them.
     """
     if not prediction.is_cuda:
         raise _lib.Y5Error('nms_padded needs a GPU tensor')
@@ -48,8 +54,11 @@ def nms_padded(prediction, conf_thres=0.1, iou_thres=0.6, classes=None, agnostic
         return empty + ((torch.zeros(0, max_det, dtype=torch.int32, device=dev), torch.zeros(0, dtype=torch.int32, device=dev)) if return_index else ())
     cap = int(max_candidates or min(N * nc, DEFAULT_CANDIDATES))
     mask = _class_mask(classes, nc, dev)
+    if stream is not None:
+        stream.wait_stream(torch.cuda.current_stream(dev))
+        prediction.record_stream(stream)
     while True:
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), torch.cuda.stream(stream):
             ws_bytes = lib.y5_nms_workspace_bytes(B, cap)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             det = torch.empty(B, max_det, 6, dtype=torch.float32, device=dev)
