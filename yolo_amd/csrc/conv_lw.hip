@@ -684,7 +684,8 @@ const DetectLaunch kDetect[] = {&launch_detect<64, 2, 4, 4, 2, 32>, &launch_dete
 
 }  // namespace
 
-int y5_detect_variant_count() { return (int)(sizeof(kDetect) / sizeof(kDetect[0])); }
+// the tile configurations of this file + the persistent kernel of conv_detect.hip as the last variant
+int y5_detect_variant_count() { return (int)(sizeof(kDetect) / sizeof(kDetect[0])) + 1; }
 
 // Detect level = 1x1 convolution (bias, no activation) + decode, one kernel.  conv.y is not written.
 int y5_launch_detect(const y5_conv_desc& c, const y5_decode_desc& d, int variant, hipStream_t s) {
@@ -717,6 +718,11 @@ int y5_launch_detect(const y5_conv_desc& c, const y5_decode_desc& d, int variant
     a.slope = 1.f;
     a.x_bytes = (int)xb;
     a.w_bytes = (int)wb;
+    if (variant == y5_detect_variant_count()) {
+        int rc = Y5_OK;
+        if (y5_try_detect_persistent(c, d, s, &rc)) return rc;
+        return y5_fail(Y5_EINVAL, "detect: the persistent kernel takes heads of 128 input channels");
+    }
     return kDetect[variant > 0 ? variant - 1 : 0](a, dec, c.batch, s);
 }
 
