@@ -186,6 +186,8 @@ VARIANT_SHAPES = [
     (2, 32, 64, 24, 41, 3, 1),
     (1, 64, 136, 19, 23, 3, 1),
     (2, 24, 48, 30, 30, 3, 2),
+    (2, 32, 64, 32, 64, 3, 2),     # the persistent stride-2 kernel's shape class (output 16 x 32)
+    (3, 32, 64, 16, 96, 3, 2),
     (3, 32, 64, 50, 38, 3, 2),
     (2, 64, 64, 33, 47, 3, 1),
     (2, 32, 24, 64, 64, 3, 1),
@@ -231,6 +233,8 @@ def test_every_kernel_variant_that_takes_the_shape(dev, shape):
         if got is not None:  # some kernel families take no residual input
             close_ulp(got, ref_res, mags=bn_mags + (pre, res), slack=order * sv.abs())
     assert taken >= 10
+    if (Ci, Co, k, s) == (32, 64, 3, 2) and (H // 2) % 8 == 0 and (W // 2) % 16 == 0:
+        assert run_conv(dev, x, w, bias=bias, slope=0.1, stride=s, variant=_lib.lib().y5_conv_num_variants()) is not None, 'the persistent stride-2 kernel takes this shape'
 
 
 @pytest.mark.parametrize('shape', [(2, 64, 96, 32), (3, 42, 74, 32), (1, 128, 66, 48), (2, 36, 130, 80), (1, 640, 640, 32)],

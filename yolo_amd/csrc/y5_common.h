@@ -95,6 +95,9 @@ int y5_conv_lw_count();
 // 3x3 stride-1 kernel with the pixel operand resident in LDS (conv_lin3.hip)
 int y5_try_conv_lin(const y5_conv_desc& d, hipStream_t s, int which, int* rc);
 int y5_conv_lin_count();
+// 3x3 stride-2 32 -> 64 persistent kernel (conv_s2c32.hip)
+int y5_try_conv_s2c32(const y5_conv_desc& d, hipStream_t s, int which, int* rc);
+int y5_conv_s2c32_count();
 int y5_launch_detect(const y5_conv_desc& c, const y5_decode_desc& d, int variant, hipStream_t s);
 int y5_detect_variant_count();
 int y5_try_detect_persistent(const y5_conv_desc& c, const y5_decode_desc& d, hipStream_t s, int* rc);
