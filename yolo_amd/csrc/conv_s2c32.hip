@@ -3,8 +3,9 @@
 //
 // One workgroup per CU walks 8 x 16 output tiles.  A loader wave copies the 17 x 33 input pixels a tile needs global -> LDS
 // by DMA, two tiles ahead (three buffers), with the columns DE-INTERLEAVED on the way: odd input columns in one plane, even
-// ones in another, so that the three horizontal taps of the stride-2 window read unit-stride rows of LDS instead of every
-// other pixel (which would put half the lanes of a ds_read_b128 on the same banks).  Eight compute waves - (two tile
+// ones in another (interleaved in blocks of eight pixels, so that a copy instruction still reads 16 consecutive pixels), so
+// that the three horizontal taps of the stride-2 window read unit-stride rows of LDS instead of every other pixel (which
+// would put half the lanes of a ds_read_b128 on the same banks).  Eight compute waves - (two tile
 // rows) x (32 output channels) - keep all 3x3 weights of their channels in registers for the whole kernel, multiply the
 // nine taps straight from the staged planes and store from registers; one LDS-only barrier per tile, no wait on own stores.
 #include <atomic>
@@ -29,17 +30,28 @@ struct S2Args {
 
 constexpr int CI = 32, CO = 64;
 constexpr int TH = 8, TW = 16;                              // output tile
-constexpr int IR = 2 * TH + 1, OC = TW + 1, EC = TW;        // input rows; columns of the odd / even plane
-constexpr int ODD_PX = IR * OC, NPX = ODD_PX + IR * EC;     // 289 + 272 = 561 staged pixels
-constexpr int ROW = CI * 2;                                 // 64 bytes per pixel: 4 slots, slot s of pixel p at s ^ ((p >> 2) & 3)
+constexpr int IR = 2 * TH + 1, IC = 2 * TW + 2, PC = IC / 2;  // staged input rows and columns (-1 .. 32, the last one unused); columns per plane
+constexpr int NPX = IR * IC;                                // 578 staged pixels
+constexpr int ROW = CI * 2;                                 // 64 bytes per pixel: 4 slots
 constexpr int PIECES = (NPX * ROW + 1023) / 1024, X_BYTES = PIECES * 1024, NBUF = 3;
+// Two staged layouts of the planes, compiled as two variants (which one is faster is a matter of how the copy's reads
+// coalesce against how the fragment reads bank; measured per shape by the caller's autotuner).  Pixel n = row * PC + j of
+// plane pl (0: odd input columns, 1: even), 16-byte slot s at s ^ ((n >> 2) & 3) in both:
+//   BLK = false: plane after plane, (pl * IR * PC + n) * 64 - a copy instruction reads 16 pixels of one plane, i.e. every
+//                other pixel of a 2 KiB stretch;
+//   BLK = true:  a 1 KiB copy piece holds 16 CONSECUTIVE input pixels as [8 odd-column pixels][8 even-column pixels]:
+//                (n >> 3) * 1024 + pl * 512 + (n & 7) * 64 - whole cache lines per copy instruction.
 constexpr int NWC = 8, NTHC = 64 * NWC, NTH = NTHC + 64;
 constexpr int PRM0 = NBUF * X_BYTES, SMEM = PRM0 + 3 * CO * 4;
 static_assert(SMEM <= 160 * 1024, "fits the CU's LDS");
 
-__device__ __forceinline__ int swz(int p, int s) { return p * ROW + ((s ^ ((p >> 2) & 3)) << 4); }
+template <bool BLK>
+__device__ __forceinline__ int swz(int pl, int n, int s) {
+    const int px = BLK ? (n >> 3) * 1024 + pl * 512 + (n & 7) * ROW : (pl * IR * PC + n) * ROW;
+    return px + ((s ^ ((n >> 2) & 3)) << 4);
+}
 
-template <int F>
+template <int F, bool BLK>
 __global__ __launch_bounds__(NTH) void conv_s2c32_kernel(const S2Args a) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int t = threadIdx.x, lane = t & 63, lr = lane & 31, lh = lane >> 5;
@@ -71,13 +83,20 @@ __global__ __launch_bounds__(NTH) void conv_s2c32_kernel(const S2Args a) {
         int rel[PIECES], flag[PIECES];
 #pragma unroll
         for (int d = 0; d < PIECES; ++d) {
-            const int slot = d * 64 + lane, p = slot >> 2, s = (slot & 3) ^ ((p >> 2) & 3);
-            const bool odd = p < ODD_PX;
-            const int q = odd ? p : p - ODD_PX, cols = odd ? OC : EC;
-            const int row = q / cols, j = q - row * cols;
-            const int col = odd ? 2 * j : 2 * j + 1;  // input column relative to 2 tx0 - 1
+            int pl, n;
+            if constexpr (BLK) {
+                pl = lane >> 5;
+                n = d * 8 + ((lane & 31) >> 2);
+            } else {
+                const int p = d * 16 + (lane >> 2);
+                pl = p >= IR * PC ? 1 : 0;
+                n = p - pl * IR * PC;
+            }
+            const int s = (lane & 3) ^ ((n >> 2) & 3);
+            const int row = n / PC, j = n - row * PC;
+            const int col = 2 * j + pl;  // input column relative to 2 tx0 - 1
             rel[d] = (row * a.W + col) * (a.x_ld * 2) + s * 16;
-            flag[d] = (row == 0 ? 1 : 0) | (odd && j == 0 ? 2 : 0) | (p >= NPX ? 4 : 0);
+            flag[d] = (row == 0 ? 1 : 0) | (col == 0 ? 2 : 0) | (row >= IR || col == IC - 1 || pl > 1 ? 4 : 0);
         }
         __builtin_amdgcn_s_setprio(3);
         auto issue = [&](int tile, int buf) {
@@ -113,8 +132,7 @@ __global__ __launch_bounds__(NTH) void conv_s2c32_kernel(const S2Args a) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int row = 2 * r + tap / 3, dx = tap % 3;
-        const int p = dx == 1 ? ODD_PX + row * EC + c : row * OC + c + (dx == 2 ? 1 : 0);
-        uoff[tap] = swz(p, lh);
+        uoff[tap] = dx == 1 ? swz<BLK>(1, row * PC + c, lh) : swz<BLK>(0, row * PC + c + (dx == 2 ? 1 : 0), lh);
     }
     Prm16<F> q;
     float negzero;
@@ -156,28 +174,28 @@ int cu_count() {  // compute units of the current device (one persistent workgro
     return n;
 }
 
-template <int F>
+template <int F, bool BLK>
 int launch(const S2Args& a, hipStream_t s) {
     static std::atomic<unsigned long long> attr_set{0};
     const unsigned long long bit = 1ull << y5_current_device();
     if (!(attr_set.load() & bit)) {
-        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_s2c32_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_s2c32_kernel<F, BLK>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         attr_set.fetch_or(bit);
     }
     const int cus = cu_count();
-    hipLaunchKernelGGL(conv_s2c32_kernel<F>, dim3((unsigned)(a.ntiles < cus ? a.ntiles : cus)), dim3(NTH), (size_t)SMEM, s, a);
+    hipLaunchKernelGGL((conv_s2c32_kernel<F, BLK>), dim3((unsigned)(a.ntiles < cus ? a.ntiles : cus)), dim3(NTH), (size_t)SMEM, s, a);
     Y5_LAUNCH_CHECK("conv_s2c32_kernel");
     return Y5_OK;
 }
 
 }  // namespace
 
-int y5_conv_s2c32_count() { return 1; }
+int y5_conv_s2c32_count() { return 2; }
 
-// which = 1.  Returns 0 when the convolution is outside what this kernel is compiled for (then *rc is untouched), 1 after a
+// which = 1 (planes one after the other) or 2 (planes interleaved in blocks of eight pixels).  Returns 0 when the convolution is outside what this kernel is compiled for (then *rc is untouched), 1 after a
 // launch attempt with its status in *rc.  d was validated by y5_launch_conv.
 int y5_try_conv_s2c32(const y5_conv_desc& d, hipStream_t s, int which, int* rc) {
-    if (which != 1 || d.ksize != 3 || d.stride != 2 || d.pad != 1 || d.cin != CI || d.cout != CO || d.res) return 0;
+    if (which < 1 || which > 2 || d.ksize != 3 || d.stride != 2 || d.pad != 1 || d.cin != CI || d.cout != CO || d.res) return 0;
     if (d.h != 2 * d.ho || d.w_in != 2 * d.wo || d.ho % TH || d.wo % TW) return 0;
     if (d.w_rows < CO || d.kpad < 9 * CI) return 0;
     const int f = (d.bias ? 1 : 0) | (d.scale ? 2 : 0);
@@ -197,6 +215,7 @@ int y5_try_conv_s2c32(const y5_conv_desc& d, hipStream_t s, int which, int* rc) 
     a.div_tpi = make_fastdiv((unsigned)(a.tiles_y * tiles_x));
     a.div_ty = make_fastdiv((unsigned)a.tiles_y);
     a.slope = d.act == Y5_ACT_LEAKY ? d.slope : 1.f;
-    *rc = f == 0 ? launch<0>(a, s) : f == 1 ? launch<1>(a, s) : f == 2 ? launch<2>(a, s) : launch<3>(a, s);
+    if (which == 1) *rc = f == 0 ? launch<0, false>(a, s) : f == 1 ? launch<1, false>(a, s) : f == 2 ? launch<2, false>(a, s) : launch<3, false>(a, s);
+    else *rc = f == 0 ? launch<0, true>(a, s) : f == 1 ? launch<1, true>(a, s) : f == 2 ? launch<2, true>(a, s) : launch<3, true>(a, s);
     return 1;
 }

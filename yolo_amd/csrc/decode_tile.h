@@ -4,11 +4,6 @@
 
 constexpr int TP = 64;  // pixels per workgroup
 
-// The workgroup barrier inside decode_from_lds.  A persistent kernel defines it as an LDS-only barrier before including
-// this file: __syncthreads() also waits for the wave's outstanding global stores, i.e. for the previous tile's output.
-#ifndef Y5_DECODE_BARRIER
-#define Y5_DECODE_BARRIER() __syncthreads()
-#endif
 constexpr int kThreads = 256;  // threads of the stand-alone decode kernels
 
 struct DecodeArgs {
@@ -75,7 +70,7 @@ __device__ __forceinline__ void decode_from_lds(const DecodeArgs& a, int b, int 
             boxdec[i] = decode_one<ET>(tile[p * a.lds_ld + an * a.no + o], o, (float)gx, (float)gy, a.anchor_wh[2 * an],
                                    a.anchor_wh[2 * an + 1], a.stride);
         }
-        Y5_DECODE_BARRIER();
+        __syncthreads();
     }
 
     const int run = np * a.no;  // contiguous outputs per anchor
