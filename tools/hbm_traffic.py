@@ -25,9 +25,10 @@ def one_step(root, counter):
 
 
 def family(name):
-    if 'csp1_kernel' in name:
-        return 'conv_csp'
-    for key in ('focus_conv', 'conv_lw', 'conv_lin3', 'conv_igemm', 'conv_halo', 'conv_ws1x1', 'conv3x3_ws', 'detect_decode', 'nms_', 'maxpool', 'upsample', 'copy_channels'):
+    for key, fam in (('csp1_kernel', 'conv_csp'), ('detect_p_kernel', 'conv_detect')):
+        if key in name:
+            return fam
+    for key in ('focus_conv', 'conv_lw', 'conv_lin3', 'conv_c64', 'conv_s2c32', 'conv_igemm', 'conv_halo', 'conv_ws1x1', 'conv3x3_ws', 'detect_decode', 'nms_', 'maxpool', 'upsample', 'copy_channels'):
         if key in name:
             return key
     return 'other'

@@ -21,7 +21,7 @@ for i in range(n):
     d = sum(s[i][1] - s[i][0] for s in steps) / len(steps) / 1e3
     name = short(steps[0][i][2])
     tot += d
-    if 'conv' in name or 'csp1' in name:
+    if 'conv' in name or 'csp1' in name or 'detect_p' in name:
         conv += d
     print('%3d %8.1f us  %s' % (i, d, name))
 span = sum(s[-1][1] - s[0][0] for s in steps) / len(steps) / 1e3
