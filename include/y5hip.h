@@ -160,6 +160,15 @@ int y5_conv_cat2_num_variants(void);
  * channel c at row parity dy, column parity dx; cout <= 96; res must be NULL; variant is ignored. */
 int y5_focus_conv_f16(const y5_conv_desc* d, y5_stream_t stream);
 
+/* Focus + its convolution AND the 3x3 stride-2 convolution that follows it, as one kernel: the tensor between the two
+ * layers is never written.  Replaces: Focus.forward models/common.py:85-86 followed by Conv.forward / fuseforward :26, :29
+ * (models/yolov5s.yaml backbone rows 0 and 1).  focus: as for y5_focus_conv_f16 (fp16 NCHW image, 32 filters; y ignored);
+ * conv: the second layer's descriptor (3x3, stride 2, 32 -> 64 channels, input = the first layer's output; x ignored) with
+ * conv.ho % 8 == 0 and conv.wo % 16 == 0.  Both layers either bias-only (fused model) or scale + shift only (BatchNorm).
+ * Values: for bias-only layers bit-identical to y5_focus_conv_f16 followed by y5_conv_f16's persistent stride-2 variant
+ * (same summation order); with scale + shift the affine step is one fused multiply-add (isolated values one fp16 step apart). */
+int y5_focus_conv2_f16(const y5_conv_desc* focus, const y5_conv_desc* conv, y5_stream_t stream);
+
 /* Image pre-processing on the device, the step before the path: img.half() followed by img /= 255.0
  * (test.py:152-154, detect.py:57-59): y[i] = fp16(float(x[i]) / 255.0f) for n uint8 values (any layout). */
 int y5_normalize_u8_f16(const void* x_u8, void* y_f16, int64_t n, y5_stream_t stream);
@@ -422,6 +431,7 @@ int y5_plan_add_conv_chain(y5_plan* p, const y5_conv_desc* first, const y5_conv_
 int y5_plan_add_conv_cat2(y5_plan* p, const y5_conv_desc* d, const void* x2, int x2_ld, int cin2);
 int y5_plan_add_csp(y5_plan* p, const y5_csp_desc* d);
 int y5_plan_add_focus_conv_u8_hwc(y5_plan* p, const y5_conv_desc* d, int input);
+int y5_plan_add_focus_conv2(y5_plan* p, const y5_conv_desc* focus, const y5_conv_desc* conv);
 /* Mark the op recorded last.  Y5_PLAN_SIDE: y5_plan_run launches it on a second stream owned by the plan, ordered
  * after everything issued before it on the caller's stream -- for an op whose result is needed only much later (the
  * Detect convs of the finer pyramid levels, which can run beside the rest of the head).  Y5_PLAN_JOIN: the caller's
@@ -455,6 +465,7 @@ int y5_plan_profile(y5_plan* p, void* const* ext, int n_ext, y5_stream_t stream,
 #define Y5_OP_CONV_CAT2 16
 #define Y5_OP_CSP 17
 #define Y5_OP_FOCUS_CONV_HWC 18
+#define Y5_OP_FOCUS_CONV2 19
 int y5_plan_op_info(const y5_plan* p, int i, int* kind, double* flops, double* bytes);
 
 #ifdef __cplusplus

@@ -342,6 +342,63 @@ def test_focus_conv_from_interleaved_uint8_equals_the_loaders_statements_first(d
     assert lib.y5_focus_conv_u8_hwc(C.byref(d), _lib.IN_U8, _lib.current_stream()) == _lib.EINVAL
 
 
+@pytest.mark.parametrize('shape', [(1, 32, 64), (2, 64, 128), (3, 96, 192), (2, 640, 640)], ids=lambda s: 'x'.join(map(str, s)))
+@pytest.mark.parametrize('mode', ['bias', 'bn'])
+def test_focus_and_the_stride2_conv_in_one_kernel(dev, shape, mode):
+    """y5_focus_conv2_f16 (yolov5s layers 0 + 1 as one kernel, the tensor between them never written) against
+    y5_focus_conv_f16 followed by y5_conv_f16: for bias-only layers bit-identical to the two kernels whose arithmetic order
+    it keeps (the Focus kernel; the persistent stride-2 variant); within the convolution tolerance of the rule-chosen
+    second kernel."""
+    lib = _lib.lib()
+    B, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    st = _lib.current_stream()
+    img = torch.randn(B, 3, H, W, generator=g).half().to(dev)
+    w0p = torch.zeros(128, 192, dtype=torch.float16, device=dev)
+    wv = torch.zeros(32, 3, 3, 16, dtype=torch.float16, device=dev)
+    wv[..., :12] = (torch.randn(32, 3, 3, 12, generator=g) / 108 ** 0.5).half().to(dev)
+    w0p[:32, :144] = wv.reshape(32, 144)
+    w1p = torch.zeros(256, 320, dtype=torch.float16, device=dev)
+    w1p[:64, :288] = (torch.randn(64, 288, generator=g) / 288 ** 0.5).half().to(dev)
+    p0 = [torch.randn(32, generator=g).to(dev), (torch.rand(32, generator=g) + 0.5).to(dev), torch.randn(32, generator=g).to(dev)]
+    p1 = [torch.randn(64, generator=g).to(dev), (torch.rand(64, generator=g) + 0.5).to(dev), torch.randn(64, generator=g).to(dev)]
+    mid = torch.zeros(B, H // 2, W // 2, 32, dtype=torch.float16, device=dev)
+    d0, d1 = _lib.ConvDesc(), _lib.ConvDesc()
+    d0.x, d0.w, d0.y = img.data_ptr(), w0p.data_ptr(), mid.data_ptr()
+    d0.batch, d0.h, d0.w_in, d0.cin = B, H, W, 3
+    d0.ho, d0.wo, d0.cout, d0.y_ld = H // 2, W // 2, 32, 32
+    d0.ksize, d0.stride, d0.pad, d0.kpad, d0.w_rows, d0.act, d0.slope = 3, 1, 1, 192, 128, _lib.ACT_LEAKY, 0.1
+    d1.x, d1.w = mid.data_ptr(), w1p.data_ptr()
+    d1.batch, d1.h, d1.w_in, d1.cin, d1.x_ld = B, H // 2, W // 2, 32, 32
+    d1.ho, d1.wo, d1.cout, d1.y_ld = H // 4, W // 4, 64, 64
+    d1.ksize, d1.stride, d1.pad, d1.kpad, d1.w_rows, d1.act, d1.slope = 3, 2, 1, 320, 256, _lib.ACT_LEAKY, 0.1
+    for d, p in ((d0, p0), (d1, p1)):
+        if mode == 'bias':
+            d.bias = p[0].data_ptr()
+        else:
+            d.scale, d.shift = p[1].data_ptr(), p[2].data_ptr()
+    outs = {}
+    for name, variant in (('rule', 0), ('persistent', lib.y5_conv_num_variants() - 1)):
+        y = torch.full((B, H // 4, W // 4, 64), float('nan'), dtype=torch.float16, device=dev)
+        d1.y, d1.variant = y.data_ptr(), variant
+        _lib.check(lib.y5_focus_conv_f16(C.byref(d0), st))
+        _lib.check(lib.y5_conv_f16(C.byref(d1), st))
+        outs[name] = y
+    y = torch.full((B, H // 4, W // 4, 64), float('nan'), dtype=torch.float16, device=dev)
+    d1.y, d1.variant, d0.y = y.data_ptr(), 0, None
+    _lib.check(lib.y5_focus_conv2_f16(C.byref(d0), C.byref(d1), st))
+    torch.cuda.synchronize()
+    assert not bool(torch.isnan(y).any())
+    if mode == 'bias':
+        assert torch.equal(y, outs['persistent'])
+    else:  # the scale + shift step is one fused multiply-add here: isolated values one fp16 step from the two-kernel path
+        close(y.permute(0, 3, 1, 2), outs['persistent'].permute(0, 3, 1, 2), rel=1e-3)
+        assert float((y == outs['persistent']).float().mean()) > 0.999
+    close(y.permute(0, 3, 1, 2), outs['rule'].permute(0, 3, 1, 2))
+    d1.ho = d1.ho + 1
+    assert lib.y5_focus_conv2_f16(C.byref(d0), C.byref(d1), st) == _lib.EINVAL
+
+
 def test_conv_into_channel_slice_leaves_neighbours_alone(dev):
     """Concat in place: writing a 32-channel result into channels [64, 96) of a 128-channel buffer."""
     lib = _lib.lib()

@@ -17,7 +17,7 @@ ACT_NONE, ACT_LEAKY = 0, 1
 F16, BF16 = 0, 1  # y5_conv_desc.dtype / y5_decode_desc.dtype
 IN_F16, IN_U8, IN_U8_HWC, IN_U8_HWC_BGR = 0, 1, 2, 3  # input layouts of y5_focus_conv_u8_hwc
 OK, EINVAL, EHIP, ENOMEM, EWORKSPACE = 0, -1, -2, -3, -4  # y5_status in include/y5hip.h
-OP_NAMES = {18: 'focus_conv', 17: 'conv', 16: 'conv', 14: 'focus_conv', 15: 'focus_conv', 13: 'conv', 12: 'detect', 8: 'focus_conv', 9: 'decode', 10: 'focus_conv', 11: 'normalize', 1: 'conv', 2: 'pack', 3: 'maxpool', 4: 'upsample', 5: 'copy', 6: 'decode', 7: 'maxpool'}
+OP_NAMES = {19: 'focus_conv', 18: 'focus_conv', 17: 'conv', 16: 'conv', 14: 'focus_conv', 15: 'focus_conv', 13: 'conv', 12: 'detect', 8: 'focus_conv', 9: 'decode', 10: 'focus_conv', 11: 'normalize', 1: 'conv', 2: 'pack', 3: 'maxpool', 4: 'upsample', 5: 'copy', 6: 'decode', 7: 'maxpool'}
 
 
 class ConvDesc(C.Structure):
@@ -68,6 +68,8 @@ SIGNATURES = {
     'y5_focus_conv_f16': (_i, [C.POINTER(ConvDesc), _s]),
     'y5_focus_conv_u8': (_i, [C.POINTER(ConvDesc), _s]),
     'y5_focus_conv_u8_hwc': (_i, [C.POINTER(ConvDesc), _i, _s]),
+    'y5_focus_conv2_f16': (_i, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), _s]),
+    'y5_plan_add_focus_conv2': (_i, [_p, C.POINTER(ConvDesc), C.POINTER(ConvDesc)]),
     'y5_plan_add_focus_conv_u8_hwc': (_i, [_p, C.POINTER(ConvDesc), _i]),
     'y5_stem_conv_f16': (_i, [C.POINTER(ConvDesc), _s]),
     'y5_stem_conv_u8': (_i, [C.POINTER(ConvDesc), _s]),

@@ -63,6 +63,11 @@ extern "C" int y5_focus_conv_u8(const y5_conv_desc* d, y5_stream_t stream) {
     return y5_launch_focus_conv(*d, static_cast<hipStream_t>(stream), true);
 }
 
+extern "C" int y5_focus_conv2_f16(const y5_conv_desc* focus, const y5_conv_desc* conv, y5_stream_t stream) {
+    Y5_REQUIRE(focus && conv, "focus_conv2: null descriptor");
+    return y5_launch_focus_conv2(*focus, *conv, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int y5_focus_conv_u8_hwc(const y5_conv_desc* d, int input, y5_stream_t stream) {
     Y5_REQUIRE(d, "focus_conv: null descriptor");
     Y5_REQUIRE(input == Y5_IN_U8_HWC || input == Y5_IN_U8_HWC_BGR, "focus_conv_u8_hwc: input must be Y5_IN_U8_HWC or Y5_IN_U8_HWC_BGR (got %d)", input);
@@ -252,6 +257,11 @@ bool set_ptr(Op& op, int field, const void* v) {
             else op.decm[l].z_out = nv;
             return true;
         }
+        case Y5_OP_FOCUS_CONV2:
+            if (field == 0) op.conv.x = v;
+            else if (field == 1) op.conv2.y = nv;
+            else return false;
+            return true;
         case Y5_OP_CONV_CHAIN:
             if (field == 0) op.conv.x = v;
             else if (field == 1) op.conv.y = nv;
@@ -312,6 +322,7 @@ int run_op(const Op& op, hipStream_t s) {
         case Y5_OP_CONV_CHAIN: return y5_launch_conv_chain(op.conv, op.conv2, op.i[1], op.i[0], s);
         case Y5_OP_CONV_CAT2: return y5_launch_conv_cat2(op.conv, op.conv2.x, op.conv2.x_ld, op.conv2.cin, s);
         case Y5_OP_CSP: return y5_launch_csp(op.csp, s);
+        case Y5_OP_FOCUS_CONV2: return y5_launch_focus_conv2(op.conv, op.conv2, s);
     }
     return y5_fail(Y5_EINVAL, "plan: unknown op kind %d", op.kind);
 }
@@ -564,6 +575,23 @@ extern "C" int y5_plan_add_conv_chain(y5_plan* p, const y5_conv_desc* first, con
         op.flops = 2.0 * m * first->cout * first->ksize * first->ksize * first->cin + 2.0 * m * second->cout * first->cout;
         op.bytes = 2.0 * ((double)first->batch * first->h * first->w_in * first->cin + m * first->cout * ((first->res ? 1 : 0) + (keep_first ? 1 : 0)) +
                           (double)first->cout * first->ksize * first->ksize * first->cin + m * second->cout + (double)second->cout * first->cout);
+        p->ops.push_back(op);
+        return Y5_OK;
+    });
+}
+
+extern "C" int y5_plan_add_focus_conv2(y5_plan* p, const y5_conv_desc* f, const y5_conv_desc* g) {
+    Y5_REQUIRE(p && f && g, "plan_add_focus_conv2: null argument");
+    return guarded([&]() {
+        Op op;
+        op.kind = Y5_OP_FOCUS_CONV2;
+        op.conv = *f;
+        op.conv2 = *g;
+        note_ptr(p, op, 0, f->x);
+        note_ptr(p, op, 1, g->y);
+        const double m0 = (double)f->batch * f->ho * f->wo, m1 = (double)g->batch * g->ho * g->wo;
+        op.flops = 2.0 * m0 * f->cout * 36.0 * f->cin + 2.0 * m1 * g->cout * 9.0 * g->cin;
+        op.bytes = 2.0 * ((double)f->batch * f->h * f->w_in * f->cin + m1 * g->cout + (double)f->cout * 36.0 * f->cin + (double)g->cout * 9.0 * g->cin);
         p->ops.push_back(op);
         return Y5_OK;
     });

@@ -1,0 +1,267 @@
+// Focus + its 3x3 convolution (3 -> 32 channels at half resolution) + the following 3x3 stride-2 convolution 32 -> 64, as ONE
+// persistent kernel: yolov5s layers 0 and 1 (models/common.py:79-86, :26; models/yolov5s.yaml backbone).  The 32-channel
+// tensor between the two layers is the largest activation of the graph (6.5 MB per 640x640 image, written once and read
+// once); here it never leaves the chip.
+//
+// Per 8 x 16 tile of layer 1's output: a loader wave copies the 38 x 80 x 3 image patch global -> LDS (one tile ahead);
+// the eight compute waves first multiply the Focus convolution for the 17 x 33 pixels of layer 0's output that the tile's
+// stride-2 windows touch - as the 6x6 / stride-2 convolution over the image that Focus + conv amount to,
+// K ordered (image row, channel, 8 columns) exactly as in conv_focus.hip, so the sums are bit-identical to that kernel's -
+// apply layer 0's post-ops and write the result into two LDS planes (odd / even columns, zeros where the window leaves
+// layer 0's output: layer 1's padding); then they multiply layer 1's nine taps from those planes exactly as conv_s2c32.hip
+// does and store from registers.  Layer 0's weights are staged once in LDS, layer 1's live in registers.  Barriers are
+// LDS-only; the only vmcnt wait is the loader's.
+#include <atomic>
+
+#include "y5_common.h"
+
+namespace {
+
+#include "conv_common.h"
+#include "epi_mix.h"
+
+struct StemArgs {
+    const f16* img;   // [B][3][H][W]
+    f16* y;           // layer 1's output (B, H/4, W/4, 64), pixel pitch y_ld
+    const f16 *w0, *w1;
+    const float *b0, *s0, *h0, *b1, *s1, *h1;
+    int w0_ld, w1_ld, H, W, Ho, Wo, y_ld, img_bytes;
+    int tiles_y, ntiles;
+    FastDiv div_tpi, div_ty;
+    float slope0, slope1;
+};
+
+constexpr int C0 = 32, C1 = 64;
+constexpr int TH = 8, TW = 16;                                   // tile of layer 1's output
+constexpr int FR = 2 * TH + 1, FC = 2 * TW + 1, FPX = FR * FC;   // layer 0 pixels a tile needs: 17 x 33
+constexpr int PC = (FC + 1) / 2;                                 // columns per plane (17)
+constexpr int NT0 = (FPX + 31) / 32;                             // 32-pixel groups of them (18)
+// image patch per channel: 38 rows of 40 pixel pairs = ten 16-byte slots, from image column 4 tx0 - 8 on (16-byte aligned;
+// the windows use columns 4 tx0 - 4 .. 4 tx0 + 65, i.e. pairs 2 .. 36): every slot lies entirely inside or outside the image
+constexpr int PR = 2 * FR + 4, PDW = 40, PSLOTS = PDW / 4, PCOL0 = 2;
+constexpr int PATCH_PIECES = (3 * PR * PSLOTS + 63) / 64, PATCH_BYTES = PATCH_PIECES * 1024;
+constexpr int W0ROW = 152;                                       // halfs per layer-0 weight row in LDS: 18 k-groups of 8 + 8 pad (19 slots: conflict-free)
+constexpr int ROW = C0 * 2;                                      // bytes per layer-0 pixel in the planes
+constexpr int PLANES_BYTES = 2 * FR * PC * ROW;                  // 36 992
+constexpr int NWC = 8, NTHC = 64 * NWC, NTH = NTHC + 64;
+constexpr int PATCH0 = 0, PLANES0 = 2 * PATCH_BYTES, PRM0 = PLANES0 + 2 * PLANES_BYTES, W00 = PRM0 + 3 * (C0 + C1) * 4;
+constexpr int SMEM = W00 + C0 * W0ROW * 2;
+static_assert(PLANES0 % 16 == 0 && PRM0 % 16 == 0 && W00 % 16 == 0 && SMEM <= 160 * 1024, "LDS layout");
+
+// layer-0 pixel n = row * PC + j of plane pl (0: odd columns of the needed region, i.e. columns 2 tx0 - 1, + 1, ...; 1: even)
+__device__ __forceinline__ int plane_off(int pl, int n, int s) { return (pl * FR * PC + n) * ROW + ((s ^ ((n >> 2) & 3)) << 4); }
+
+template <int F0, int F1>
+__global__ __launch_bounds__(NTH) void stem2_kernel(const StemArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int t = threadIdx.x, lane = t & 63, lr = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int nwg = gridDim.x, g = xcd_remap(blockIdx.x, nwg);
+    const int first = (int)((long long)g * a.ntiles / nwg), last = (int)((long long)(g + 1) * a.ntiles / nwg);
+
+    float* prm = reinterpret_cast<float*>(smem + PRM0);  // [bias | scale | shift] of layer 0 (C0 each), then of layer 1 (C1 each)
+    for (int i = t; i < C0; i += NTH) {
+        prm[i] = a.b0 ? a.b0[i] : 0.f;
+        prm[C0 + i] = a.s0 ? a.s0[i] : 1.f;
+        prm[2 * C0 + i] = a.s0 ? a.h0[i] : 0.f;
+    }
+    for (int i = t; i < C1; i += NTH) {
+        prm[3 * C0 + i] = a.b1 ? a.b1[i] : 0.f;
+        prm[3 * C0 + C1 + i] = a.s1 ? a.s1[i] : 1.f;
+        prm[3 * C0 + 2 * C1 + i] = a.s1 ? a.h1[i] : 0.f;
+    }
+
+    // layer 0 weights: row i = output channel perm(i); k-group g = r6 * 3 + c (image row r6 of the 6x6 window, channel c)
+    // holds the 8 columns q6 (6 used) of the packed row k = (r*3 + q)*16 + (dy + 2*dx)*3 + c with r6 = 2r + dy, q6 = 2q + dx
+    f16* w0l = reinterpret_cast<f16*>(smem + W00);
+    for (int idx = t; idx < C0 * 144; idx += NTH) {
+        const int n = idx / 144, rem = idx - n * 144;
+        const int grp = rem >> 3, q6 = rem & 7, r6 = grp / 3, c = grp - 3 * r6;
+        w0l[n * W0ROW + rem] = q6 < 6 ? a.w0[(size_t)perm_row(n) * a.w0_ld + ((r6 >> 1) * 3 + (q6 >> 1)) * 16 + ((r6 & 1) + 2 * (q6 & 1)) * 3 + c] : (f16)0.f;
+    }
+
+    int tb, ty0, tx0;  // image and first layer-1 output pixel of a tile
+    auto locate = [&](int tile) {
+        tb = (int)fdiv((unsigned)tile, a.div_tpi);
+        const int rem = tile - tb * (int)a.div_tpi.d;
+        const int tx = (int)fdiv((unsigned)rem, a.div_ty);
+        ty0 = (rem - tx * a.tiles_y) * TH;
+        tx0 = tx * TW;
+    };
+
+    if (wave == NWC) {
+        // ------------------------------------------------------------------ loader wave: the image patch, [channel][row][pair]
+        const i32x4 ir = make_buf(a.img, a.img_bytes);
+        // piece d, lane: slot index d * 64 + lane -> (channel, patch row, slot of 8 columns); byte offset from image element
+        // (channel 0, row 4 ty0 - 4, column 4 tx0 - 8)
+        int rel[PATCH_PIECES], rc[PATCH_PIECES];
+#pragma unroll
+        for (int d = 0; d < PATCH_PIECES; ++d) {
+            const int idx = d * 64 + lane, ch = idx / (PR * PSLOTS), rem = idx - ch * (PR * PSLOTS);
+            const int row = rem / PSLOTS, sl = rem - row * PSLOTS;
+            rel[d] = ((ch * a.H + row) * a.W + 8 * sl) * 2;
+            rc[d] = row | (sl << 8) | (ch >= 3 ? 1 << 16 : 0);
+        }
+        __builtin_amdgcn_s_setprio(3);
+        auto issue = [&](int tile, int buf) {
+            locate(tile);
+            const int iy0 = 4 * ty0 - 4, ix0 = 4 * tx0 - 8;
+            const int base = ((tb * 3 * a.H + iy0) * a.W + ix0) * 2;
+            const bool inner = iy0 >= 0 && iy0 + PR <= a.H && ix0 >= 0 && ix0 + 2 * PDW <= a.W;
+#pragma unroll
+            for (int d = 0; d < PATCH_PIECES; ++d) {
+                bool ok = !(rc[d] >> 16);
+                if (!inner) {
+                    const int row = rc[d] & 255, sl = (rc[d] >> 8) & 255;
+                    ok = ok && (unsigned)(iy0 + row) < (unsigned)a.H && (unsigned)(ix0 + 8 * sl) < (unsigned)a.W;
+                }
+                dma16_buf(ir, ok ? (unsigned)(base + rel[d]) : Y5_BUF_OOB, (unsigned)(PATCH0 + buf * PATCH_BYTES + d * 1024));
+            }
+        };
+        if (first < last) issue(first, 0);
+        int cur = 0;
+        for (int tile = first; tile < last; ++tile, cur ^= 1) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // A: the patch has landed
+            if (tile + 1 < last) issue(tile + 1, cur ^ 1);                            // last read by layer 0 of tile - 1
+            asm volatile("s_barrier" ::: "memory");                                   // B
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- compute waves
+    // MFMA step s of layer 0 multiplies k-groups s (lanes 0-31) and s + 9 (lanes 32-63)
+    const f16* w0p = w0l + lr * W0ROW + 9 * lh * 8;
+    const int nt1 = wave >> 1, mt1 = wave & 1;  // layer 1: output rows 2 nt1, 2 nt1 + 1 of the tile; channels [32 mt1, +32)
+    const int r1 = 2 * nt1 + (lr >> 4), c1 = lr & 15;
+    f16x8 w1f[9 * C0 / 16];
+#pragma unroll
+    for (int ks = 0; ks < 9 * C0 / 16; ++ks) w1f[ks] = *reinterpret_cast<const f16x8*>(a.w1 + (size_t)(mt1 * 32 + perm_row(lr)) * a.w1_ld + ks * 16 + lh * 8);
+    int uoff[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int row = 2 * r1 + tap / 3, dx = tap % 3;
+        uoff[tap] = dx == 1 ? plane_off(1, row * PC + c1, lh) : plane_off(0, row * PC + c1 + (dx == 2 ? 1 : 0), lh);
+    }
+    float negzero;
+    asm volatile("v_mov_b32 %0, 0x80000000" : "=v"(negzero));
+    int cur = 0;
+    for (int tile = first; tile < last; ++tile, cur ^= 1) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // A
+        locate(tile);
+        const unsigned char* patch = smem + PATCH0 + cur * PATCH_BYTES;
+        unsigned char* planes = smem + PLANES0 + cur * PLANES_BYTES;
+        // ---- layer 0 on the 17 x 33 pixels (row fy = 2 ty0 - 1 + frow, column fx = 2 tx0 - 1 + fcol of its output)
+#pragma unroll
+        for (int i = 0; i < (NT0 + NWC - 1) / NWC; ++i) {
+            const int nt = wave + NWC * i;
+            if (nt >= NT0) break;
+            const int n = nt * 32 + lr;
+            const int frow = min(n / FC, FR - 1), fcol = n - (n / FC) * FC;  // groups past the region repeat its last row (never written)
+            // patch rows 2 frow + r6, pair columns fcol .. fcol + 3 (8 image columns from 2 fcol on) of channel s % 3
+            const unsigned char* bp = patch + ((2 * frow + 3 * lh) * PDW + fcol + PCOL0) * 4;
+            f32x16 acc = zero16();
+#pragma unroll
+            for (int s = 0; s < 9; ++s) {
+                const unsigned* p = reinterpret_cast<const unsigned*>(bp + ((s % 3) * PR + s / 3) * PDW * 4);
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 u = {p[0], p[1], p[2], p[3]};
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(w0p + s * 8), __builtin_bit_cast(f16x8, u), acc, 0, 0, 0);
+            }
+            f16x8 lo, hi;
+            finish<F0>(acc, prm, C0, 16 * lh, a.slope0, negzero, lo, hi);
+            const int fy = 2 * ty0 - 1 + frow, fx = 2 * tx0 - 1 + fcol;
+            if (fy < 0 || fx < 0) {  // outside layer 0's output: layer 1's zero padding (its bottom / right windows stay inside)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) lo[e] = hi[e] = (f16)0.f;
+            }
+            if (n < FPX) {
+                const int pl = fcol & 1, np = frow * PC + (fcol >> 1);
+                *reinterpret_cast<f16x8*>(planes + plane_off(pl, np, 2 * lh)) = lo;
+                *reinterpret_cast<f16x8*>(planes + plane_off(pl, np, 2 * lh + 1)) = hi;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // B: the planes are complete
+        // ---- layer 1
+        f32x16 acc = zero16();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int ks = 0; ks < C0 / 16; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1f[tap * (C0 / 16) + ks], *reinterpret_cast<const f16x8*>(planes + (uoff[tap] ^ (ks << 5))), acc, 0, 0, 0);
+        f16x8 lo, hi;
+        finish<F1>(acc, prm + 3 * C0, C1, mt1 * 32 + 16 * lh, a.slope1, negzero, lo, hi);
+        f16* yp = a.y + ((size_t)(tb * a.Ho + ty0 + r1) * a.Wo + tx0 + c1) * a.y_ld + mt1 * 32 + 16 * lh;
+        *reinterpret_cast<f16x8*>(yp) = lo;
+        *reinterpret_cast<f16x8*>(yp + 8) = hi;
+    }
+}
+
+int cu_count() {  // compute units of the current device (one persistent workgroup each)
+    static std::atomic<int> cached[64];
+    const int dev = y5_current_device();
+    int n = cached[dev].load();
+    if (n == 0) {
+        int real = 0;
+        if (hipGetDevice(&real) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, real) != hipSuccess || n <= 0) n = 256;
+        cached[dev].store(n);
+    }
+    return n;
+}
+
+template <int F0, int F1>
+int launch(const StemArgs& a, hipStream_t s) {
+    static std::atomic<unsigned long long> attr_set{0};
+    const unsigned long long bit = 1ull << y5_current_device();
+    if (!(attr_set.load() & bit)) {
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stem2_kernel<F0, F1>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        attr_set.fetch_or(bit);
+    }
+    const int cus = cu_count();
+    hipLaunchKernelGGL((stem2_kernel<F0, F1>), dim3((unsigned)(a.ntiles < cus ? a.ntiles : cus)), dim3(NTH), (size_t)SMEM, s, a);
+    Y5_LAUNCH_CHECK("stem2_kernel");
+    return Y5_OK;
+}
+
+}  // namespace
+
+// f: the Focus convolution as y5_focus_conv_f16 takes it (x = the fp16 NCHW image, y ignored); g: the 3x3 stride-2
+// convolution of its output (x ignored).
+int y5_launch_focus_conv2(const y5_conv_desc& f, const y5_conv_desc& g, hipStream_t s) {
+    Y5_REQUIRE(f.dtype == Y5_F16 && g.dtype == Y5_F16, "focus_conv2: fp16 only");
+    Y5_REQUIRE(f.x && f.w && g.w && g.y, "focus_conv2: null image, weight or output pointer");
+    Y5_REQUIRE(f.cin == 3 && f.ksize == 3 && f.stride == 1 && f.pad == 1 && f.cout == C0, "focus_conv2: the first layer is Focus + 3x3 stride 1 with %d filters", C0);
+    Y5_REQUIRE(g.ksize == 3 && g.stride == 2 && g.pad == 1 && g.cin == C0 && g.cout == C1, "focus_conv2: the second layer is 3x3 stride 2, %d -> %d channels", C0, C1);
+    Y5_REQUIRE(f.batch > 0 && g.batch == f.batch && f.h % 4 == 0 && f.w_in % 4 == 0 && f.ho == f.h / 2 && f.wo == f.w_in / 2 && g.h == f.ho && g.w_in == f.wo &&
+                   g.ho == f.h / 4 && g.wo == f.w_in / 4, "focus_conv2: inconsistent geometry");
+    Y5_REQUIRE(g.ho % TH == 0 && g.wo % TW == 0, "focus_conv2: output height must be a multiple of %d and width of %d (got %d x %d)", TH, TW, g.ho, g.wo);
+    Y5_REQUIRE(f.kpad >= 144 && f.w_rows >= C0 && g.kpad >= 9 * C0 && g.w_rows >= C1, "focus_conv2: weights not packed (Focus: 16-channel space-to-depth layout)");
+    Y5_REQUIRE(!f.res && !g.res, "focus_conv2: no residual input");
+    Y5_REQUIRE(g.y_ld >= C1 && g.y_ld % 8 == 0 && y5_aligned16(g.y) && y5_aligned16(g.w) && (reinterpret_cast<uintptr_t>(f.x) & 3) == 0 && (reinterpret_cast<uintptr_t>(f.w) & 1) == 0,
+               "focus_conv2: misaligned pointer or pitch");
+    for (const y5_conv_desc* d : {&f, &g}) {
+        Y5_REQUIRE((d->scale == nullptr) == (d->shift == nullptr), "focus_conv2: scale and shift come together");
+        Y5_REQUIRE(d->act == Y5_ACT_NONE || (d->act == Y5_ACT_LEAKY && d->slope > 0.f && d->slope <= 1.f), "focus_conv2: bad activation");
+    }
+    const long long ib = (long long)f.batch * 3 * f.h * f.w_in * 2;
+    Y5_REQUIRE(ib < 0x7fffffffLL, "focus_conv2: image batch of 2 GiB or more");
+    StemArgs a{};
+    a.img = static_cast<const f16*>(f.x);
+    a.y = static_cast<f16*>(g.y);
+    a.w0 = static_cast<const f16*>(f.w);
+    a.w1 = static_cast<const f16*>(g.w);
+    a.b0 = f.bias; a.s0 = f.scale; a.h0 = f.shift; a.b1 = g.bias; a.s1 = g.scale; a.h1 = g.shift;
+    a.w0_ld = f.kpad; a.w1_ld = g.kpad; a.H = f.h; a.W = f.w_in; a.Ho = g.ho; a.Wo = g.wo; a.y_ld = g.y_ld; a.img_bytes = (int)ib;
+    a.tiles_y = g.ho / TH;
+    const int tiles_x = g.wo / TW;
+    const long long total = (long long)f.batch * a.tiles_y * tiles_x;
+    Y5_REQUIRE(total > 0 && total < 0x7fffffffLL, "focus_conv2: too many tiles");
+    a.ntiles = (int)total;
+    a.div_tpi = make_fastdiv((unsigned)(a.tiles_y * tiles_x));
+    a.div_ty = make_fastdiv((unsigned)a.tiles_y);
+    a.slope0 = f.act == Y5_ACT_LEAKY ? f.slope : 1.f;
+    a.slope1 = g.act == Y5_ACT_LEAKY ? g.slope : 1.f;
+    const int f0 = (f.bias ? 1 : 0) | (f.scale ? 2 : 0), f1 = (g.bias ? 1 : 0) | (g.scale ? 2 : 0);
+    if (f0 == 1 && f1 == 1) return launch<1, 1>(a, s);
+    if (f0 == 2 && f1 == 2) return launch<2, 2>(a, s);
+    return y5_fail(Y5_EINVAL, "focus_conv2: compiled for bias-only layers (fused model) or scale+shift-only layers (BatchNorm), got %d / %d", f0, f1);
+}

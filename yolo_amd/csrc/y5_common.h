@@ -113,6 +113,8 @@ int y5_conv_cat2_variant_count();
 // input: Y5_IN_F16 / Y5_IN_U8 (NCHW planes) or Y5_IN_U8_HWC / Y5_IN_U8_HWC_BGR (interleaved bytes)
 int y5_launch_focus_conv(const y5_conv_desc& d, hipStream_t s, int input = Y5_IN_F16);
 int y5_launch_stem_conv(const y5_conv_desc& d, hipStream_t s, bool u8 = false);
+// Focus + conv and the following 3x3 stride-2 conv as one kernel (conv_stem2.hip)
+int y5_launch_focus_conv2(const y5_conv_desc& f, const y5_conv_desc& g, hipStream_t s);
 int y5_launch_normalize_u8(const void* x, void* y, long long n, hipStream_t s);
 int y5_launch_pack_image(const void* x, void* y, int batch, int c, int h, int w, int focus, int y_ld, hipStream_t s);
 int y5_launch_maxpool(const void* x, int x_ld, void* y, int y_ld, int batch, int h, int w, int c, int k, hipStream_t s, int dtype = Y5_F16);

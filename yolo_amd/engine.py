@@ -352,6 +352,9 @@ class Plan:
         if image is not None:
             d.batch, d.h, d.w_in, d.cin, d.x_ld = image.shape[0], image.shape[2], image.shape[3], image.shape[1], 0
             u8 = image.dtype is torch.uint8
+            if self._defer is not None:  # the caller records the descriptor itself (_focus_conv2)
+                self._defer.append(('%s focus+conv3x3 %d->%d @%dx%d' % (label, x.c_log, out.c_log, ho, wo), d, x))
+                return
             if self.hwc:
                 if stem:
                     raise Unsupported('an interleaved uint8 image is read by the fused Focus kernel only')
@@ -542,6 +545,54 @@ class Plan:
         self.labels.append('%s pack focus' % name)
         self._conv_block(name, m.conv, packed, out)
 
+    def _focus_conv2(self, name0, m0, name1, m1, image, out1):
+        """Focus (layer 0) and the 3x3 stride-2 Conv that reads it (layer 1) as ONE kernel (y5_focus_conv2_f16) when the
+        pair has the shape that kernel is compiled for and it measures faster than the two kernels; otherwise the two
+        layers are recorded as usual.  The tensor between them is only allocated for the two-kernel plan."""
+        B, cin, H, W = image.shape
+        c0 = m0.conv.conv.out_channels
+        segs = [(4 * cin, pad8(4 * cin))]
+        shape_only = Act(None, 0, segs[0][1], B, H // 2, W // 2, segs)
+        keep_n = len(self.keep)
+        mid = self._new_act(B, H // 2, W // 2, [(c0, pad8(c0))])
+        self._defer = []
+        try:
+            self._conv_block(name0, m0.conv, shape_only, mid, image=image)
+            self._conv_block(name1, m1, mid, out1)
+        finally:
+            defs, self._defer = self._defer, None
+        (t0, d0, _), (t1, d1, _) = defs
+        stream = _lib.current_stream()
+        fused = self.lib.y5_focus_conv2_f16(C.byref(d0), C.byref(d1), stream) == 0
+        d1.variant = self._tune(d1, mid)
+        two_ms = _TUNED_MS.get(self._last_key, float('inf'))
+        if fused and os.environ.get('Y5_AUTOTUNE', '1') != '0':
+            key = ('stem2', B, H, W, out1.ld, bool(d0.bias), bool(d1.bias))
+            if key not in _TUNED:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+                def timed(fn, n=8):
+                    fn()
+                    e0.record()
+                    for _ in range(n):
+                        fn()
+                    e1.record()
+                    e1.synchronize()
+                    return e0.elapsed_time(e1) / n
+                focus_ms = timed(lambda: self.lib.y5_focus_conv_f16(C.byref(d0), stream))
+                one_ms = timed(lambda: self.lib.y5_focus_conv2_f16(C.byref(d0), C.byref(d1), stream))
+                _TUNED[key], _TUNED_MS[key] = int(one_ms < focus_ms + two_ms), min(one_ms, focus_ms + two_ms)
+            fused = bool(_TUNED[key])
+        if fused:
+            del self.keep[keep_n]  # the tensor between the layers: not needed (the packed weights behind it are)
+            _lib.check(self.lib.y5_plan_add_focus_conv2(self.handle, C.byref(d0), C.byref(d1)))
+            self.labels.append('%s -> %s, one kernel' % (t0, t1))
+            return
+        _lib.check(self.lib.y5_plan_add_focus_conv(self.handle, C.byref(d0)))
+        self.labels.append(t0)
+        _lib.check(self.lib.y5_plan_add_conv(self.handle, C.byref(d1)))
+        self.labels.append('%s v%d' % (t1, d1.variant))
+
     def _out_for(self, idx, batch, h, w, c_log):
         """Destination of top-level layer idx: its slice of a later concat buffer, or a fresh buffer."""
         home = self.homes.get(idx)
@@ -670,6 +721,7 @@ class Plan:
             srcs = [len(layers) - 1 + j if j < 0 else j for j in (head.f if isinstance(head.f, (list, tuple)) else [head.f])]
             if len(srcs) == head.nl and len(set(srcs)) == len(srcs):
                 early = {j: lvl for lvl, j in enumerate(srcs) if j != max(srcs)}
+        skip = set()
         for i, m in enumerate(layers):
             name = '%d.%s' % (i, type(m).__name__)
             f = m.f
@@ -680,9 +732,23 @@ class Plan:
                 self._detect(m, [get(j) for j in f])
                 continue
             c_log, h, w = shapes[i]
+            if i in skip:
+                continue
             if isinstance(m, common.Focus):
                 if i != 0 or f != -1:
                     raise Unsupported('Focus must be the first layer')
+                nxt = layers[1] if len(layers) > 2 else None
+                if (isinstance(nxt, common.Conv) and nxt.f == -1 and image.dtype is torch.float16 and not self.hwc and self.cin == 3
+                        and _conv_geometry(m.conv.conv) == (3, 1) and m.conv.conv.out_channels == 32 and _conv_geometry(nxt.conv) == (3, 2)
+                        and nxt.conv.out_channels == 64 and nxt.conv.groups == 1 and 0 not in self.homes
+                        and not any(0 in [k if k >= 0 else j + 2 + k for k in (l.f if isinstance(l.f, (list, tuple)) else [l.f])] for j, l in enumerate(layers[2:]))
+                        and os.environ.get('Y5_STEM2_FUSE', '1') != '0' and os.environ.get('Y5_FOCUS_FUSE', '1') != '0'):
+                    c1_log, h1, w1 = shapes[1]
+                    out1 = self._out_for(1, B, h1, w1, c1_log)
+                    self._focus_conv2(name, m, '1.%s' % type(nxt).__name__, nxt, image, out1)
+                    outs[0], outs[1] = None, out1
+                    skip.add(1)
+                    continue
                 out = self._out_for(i, B, h, w, c_log)
                 self._focus(name, m, image, out)
             elif isinstance(m, common.Conv):
