@@ -3,15 +3,17 @@
 // tensor between the two layers is the largest activation of the graph (6.5 MB per 640x640 image, written once and read
 // once); here it never leaves the chip.
 //
-// Per 8 x 16 tile of layer 1's output: a loader wave copies the 38 x 80 x 3 image patch global -> LDS (one tile ahead);
-// the eight compute waves first multiply the Focus convolution for the 17 x 33 pixels of layer 0's output that the tile's
+// Per 8 x 16 tile of layer 1's output: the eight waves share the copy of the 38 x 80 x 3 image patch global -> LDS (one
+// tile ahead, two or three 1 KiB pieces each), then multiply the Focus convolution for the 17 x 33 pixels of layer 0's output that the tile's
 // stride-2 windows touch - as the 6x6 / stride-2 convolution over the image that Focus + conv amount to,
 // K ordered (image row, channel, 8 columns) exactly as in conv_focus.hip, so the sums are bit-identical to that kernel's -
 // apply layer 0's post-ops and write the result into two LDS planes (odd / even columns, zeros where the window leaves
 // layer 0's output: layer 1's padding); then they multiply layer 1's nine taps from those planes exactly as conv_s2c32.hip
-// does and store from registers.  Layer 0's weights are staged once in LDS, layer 1's live in registers.  Barriers are
-// LDS-only; the only vmcnt wait is the loader's.
+// does and store from registers.  Both layers' weights live in registers (eight waves of 64 lanes: 256 registers each),
+// and a wave reads the image words of its next 32-pixel group while the current group multiplies.  Barriers are LDS-only;
+// the one vmcnt wait per tile sits after layer 1's multiplies, a whole tile after the copy it waits for was issued.
 #include <atomic>
+#include <type_traits>
 
 #include "y5_common.h"
 
@@ -42,14 +44,24 @@ constexpr int PR = 2 * FR + 4, PDW = 40, PSLOTS = PDW / 4, PCOL0 = 2;
 constexpr int PATCH_PIECES = (3 * PR * PSLOTS + 63) / 64, PATCH_BYTES = PATCH_PIECES * 1024;
 constexpr int W0ROW = 152;                                       // halfs per layer-0 weight row in LDS: 18 k-groups of 8 + 8 pad (19 slots: conflict-free)
 constexpr int ROW = C0 * 2;                                      // bytes per layer-0 pixel in the planes
-constexpr int PLANES_BYTES = 2 * FR * PC * ROW;                  // 36 992
-constexpr int NWC = 8, NTHC = 64 * NWC, NTH = NTHC + 64;
+constexpr int PLANES_USED = 2 * FR * PC * ROW;                   // 36 992
+constexpr int PLANES_BYTES = PLANES_USED + 64 * 32;              // + a 32-byte slot per lane for the lanes past the region
+constexpr int NWC = 8, NTH = 64 * NWC;
+constexpr int MYP = (PATCH_PIECES + NWC - 1) / NWC;              // patch pieces a wave copies (piece d belongs to wave d % 8)
 constexpr int PATCH0 = 0, PLANES0 = 2 * PATCH_BYTES, PRM0 = PLANES0 + 2 * PLANES_BYTES, W00 = PRM0 + 3 * (C0 + C1) * 4;
 constexpr int SMEM = W00 + C0 * W0ROW * 2;
 static_assert(PLANES0 % 16 == 0 && PRM0 % 16 == 0 && W00 % 16 == 0 && SMEM <= 160 * 1024, "LDS layout");
 
 // layer-0 pixel n = row * PC + j of plane pl (0: odd columns of the needed region, i.e. columns 2 tx0 - 1, + 1, ...; 1: even)
 __device__ __forceinline__ int plane_off(int pl, int n, int s) { return (pl * FR * PC + n) * ROW + ((s ^ ((n >> 2) & 3)) << 4); }
+
+#ifdef Y5_STAMPS
+// Diagnostic build only: per compute wave, cycles in {barrier A, layer 0, barrier B, layer 1 + store} summed over tiles
+__device__ unsigned long long y5_stem2_stamp_buf[256 * 8 * 8];
+#define STEM_STAMP(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[i] += now_ - st_last; st_last = now_; }
+#else
+#define STEM_STAMP(i)
+#endif
 
 template <int F0, int F1>
 __global__ __launch_bounds__(NTH) void stem2_kernel(const StemArgs a) {
@@ -89,48 +101,52 @@ __global__ __launch_bounds__(NTH) void stem2_kernel(const StemArgs a) {
         tx0 = tx * TW;
     };
 
-    if (wave == NWC) {
-        // ------------------------------------------------------------------ loader wave: the image patch, [channel][row][pair]
-        const i32x4 ir = make_buf(a.img, a.img_bytes);
-        // piece d, lane: slot index d * 64 + lane -> (channel, patch row, slot of 8 columns); byte offset from image element
-        // (channel 0, row 4 ty0 - 4, column 4 tx0 - 8)
-        int rel[PATCH_PIECES], rc[PATCH_PIECES];
+    // ------------------------------------------------------------------ the image patch, [channel][row][pair]
+    const i32x4 ir = make_buf(a.img, a.img_bytes);
+    // piece d, lane: slot index d * 64 + lane -> (channel, patch row, slot of 8 columns); byte offset from image element
+    // (channel 0, row 4 ty0 - 4, column 4 tx0 - 8).  Wave w copies pieces NWC - 1 - w, + NWC, ... (the waves with one more
+    // 32-pixel group of layer 0 copy one piece fewer)
+    int rel[MYP], rc[MYP];
 #pragma unroll
-        for (int d = 0; d < PATCH_PIECES; ++d) {
-            const int idx = d * 64 + lane, ch = idx / (PR * PSLOTS), rem = idx - ch * (PR * PSLOTS);
-            const int row = rem / PSLOTS, sl = rem - row * PSLOTS;
-            rel[d] = ((ch * a.H + row) * a.W + 8 * sl) * 2;
-            rc[d] = row | (sl << 8) | (ch >= 3 ? 1 << 16 : 0);
-        }
-        __builtin_amdgcn_s_setprio(3);
-        auto issue = [&](int tile, int buf) {
-            locate(tile);
-            const int iy0 = 4 * ty0 - 4, ix0 = 4 * tx0 - 8;
-            const int base = ((tb * 3 * a.H + iy0) * a.W + ix0) * 2;
-            const bool inner = iy0 >= 0 && iy0 + PR <= a.H && ix0 >= 0 && ix0 + 2 * PDW <= a.W;
-#pragma unroll
-            for (int d = 0; d < PATCH_PIECES; ++d) {
-                bool ok = !(rc[d] >> 16);
-                if (!inner) {
-                    const int row = rc[d] & 255, sl = (rc[d] >> 8) & 255;
-                    ok = ok && (unsigned)(iy0 + row) < (unsigned)a.H && (unsigned)(ix0 + 8 * sl) < (unsigned)a.W;
-                }
-                dma16_buf(ir, ok ? (unsigned)(base + rel[d]) : Y5_BUF_OOB, (unsigned)(PATCH0 + buf * PATCH_BYTES + d * 1024));
-            }
-        };
-        if (first < last) issue(first, 0);
-        int cur = 0;
-        for (int tile = first; tile < last; ++tile, cur ^= 1) {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // A: the patch has landed
-            if (tile + 1 < last) issue(tile + 1, cur ^ 1);                            // last read by layer 0 of tile - 1
-            asm volatile("s_barrier" ::: "memory");                                   // B
-        }
-        return;
+    for (int j = 0; j < MYP; ++j) {
+        const int d = NWC - 1 - wave + NWC * j;
+        const int idx = d * 64 + lane, ch = idx / (PR * PSLOTS), rem = idx - ch * (PR * PSLOTS);
+        const int row = rem / PSLOTS, sl = rem - row * PSLOTS;
+        const bool unused = ch >= 3 || d >= PATCH_PIECES;  // slots past the third channel: read as out of range, i.e. zeros
+        rel[j] = unused ? 0x7fffffff : ((ch * a.H + row) * a.W + 8 * sl) * 2;  // base + this stays below 2^32 and at or above img_bytes
+        rc[j] = row | (sl << 8) | (unused ? 1 << 16 : 0);
     }
+    auto issue = [&](int tile, int buf) {
+        locate(tile);
+        const int iy0 = 4 * ty0 - 4, ix0 = 4 * tx0 - 8;
+        const int base = ((tb * 3 * a.H + iy0) * a.W + ix0) * 2;
+        const bool inner = iy0 >= 0 && iy0 + PR <= a.H && ix0 >= 0 && ix0 + 2 * PDW <= a.W;
+        if (inner) {  // no clipping: a lane's address is the patch origin plus its fixed offset
+#pragma unroll
+            for (int j = 0; j < MYP; ++j) {
+                const int d = NWC - 1 - wave + NWC * j;
+                if (d >= PATCH_PIECES) break;
+                dma16_buf(ir, (unsigned)(base + rel[j]), (unsigned)(PATCH0 + buf * PATCH_BYTES + d * 1024));
+            }
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < MYP; ++j) {
+            const int d = NWC - 1 - wave + NWC * j;
+            if (d >= PATCH_PIECES) break;
+            const int row = rc[j] & 255, sl = (rc[j] >> 8) & 255;
+            const bool ok = !(rc[j] >> 16) && (unsigned)(iy0 + row) < (unsigned)a.H && (unsigned)(ix0 + 8 * sl) < (unsigned)a.W;
+            dma16_buf(ir, ok ? (unsigned)(base + rel[j]) : Y5_BUF_OOB, (unsigned)(PATCH0 + buf * PATCH_BYTES + d * 1024));
+        }
+    };
+    if (first < last) issue(first, 0);
 
-    // ---------------------------------------------------------------------- compute waves
+    // ---------------------------------------------------------------------- weights and per-lane offsets
+    __syncthreads();
     // MFMA step s of layer 0 multiplies k-groups s (lanes 0-31) and s + 9 (lanes 32-63)
-    const f16* w0p = w0l + lr * W0ROW + 9 * lh * 8;
+    f16x8 w0f[9];
+#pragma unroll
+    for (int s9 = 0; s9 < 9; ++s9) w0f[s9] = *reinterpret_cast<const f16x8*>(w0l + lr * W0ROW + (9 * lh + s9) * 8);
     const int nt1 = wave >> 1, mt1 = wave & 1;  // layer 1: output rows 2 nt1, 2 nt1 + 1 of the tile; channels [32 mt1, +32)
     const int r1 = 2 * nt1 + (lr >> 4), c1 = lr & 15;
     f16x8 w1f[9 * C0 / 16];
@@ -142,45 +158,85 @@ __global__ __launch_bounds__(NTH) void stem2_kernel(const StemArgs a) {
         const int row = 2 * r1 + tap / 3, dx = tap % 3;
         uoff[tap] = dx == 1 ? plane_off(1, row * PC + c1, lh) : plane_off(0, row * PC + c1 + (dx == 2 ? 1 : 0), lh);
     }
+    // layer 0: this wave's 32-pixel groups wave, wave + 8, (wave + 16) of the 17 x 33 region; pixel n = 32 group + lr sits
+    // in row frow, column fcol (row fy = 2 ty0 - 1 + frow, column fx = 2 tx0 - 1 + fcol of layer 0's output)
+    constexpr int NU = (NT0 + NWC - 1) / NWC;
+    int boff[NU], poff[NU], edge = 0;  // edge: bit 2 i = group i's pixel is in the region's first row, bit 2 i + 1 = in its first column
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        const int n = (wave + NWC * i) * 32 + lr;
+        const int frow = min(n / FC, FR - 1), fcol = n - (n / FC) * FC;  // lanes past the region repeat its last row (never written)
+        // patch rows 2 frow + r6, pair columns fcol .. fcol + 3 (8 image columns from 2 fcol on)
+        boff[i] = ((2 * frow + 3 * lh) * PDW + fcol + PCOL0) * 4;
+        poff[i] = n < FPX ? plane_off(fcol & 1, frow * PC + (fcol >> 1), 2 * lh) : PLANES_USED + lane * 32;  // past the region: a slot nobody reads
+        edge |= ((frow == 0 ? 1 : 0) | (fcol == 0 ? 2 : 0)) << (2 * i);
+    }
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    struct __attribute__((packed, aligned(4))) Quad { unsigned q0, q1, q2, q3; };
     float negzero;
     asm volatile("v_mov_b32 %0, 0x80000000" : "=v"(negzero));
+    auto layer0 = [&](auto nu_c, const unsigned char* patch, unsigned char* planes, int zmask) {
+        constexpr int N = decltype(nu_c)::value;
+        // the image words of multiply g = 9 group + s9 (channel s9 % 3, window rows s9 / 3 in lanes 0-31 and 3 + s9 / 3 in lanes
+        // 32-63) sit in slot g % RING; a slot is refilled for multiply g + RING right after multiply g has read it
+        constexpr int RING = 4;
+        u32x4 pd[RING];
+        auto fetch = [&](int g) {
+            const int i = g / 9, s9 = g % 9;
+            const Quad q = *reinterpret_cast<const Quad*>(patch + boff[i] + ((s9 % 3) * PR + s9 / 3) * PDW * 4);
+            pd[g % RING] = u32x4{q.q0, q.q1, q.q2, q.q3};
+        };
+        auto put = [&](int i, const f32x16& acc) {
+            f16x8 lo, hi;
+            finish<F0>(acc, prm, C0, 16 * lh, a.slope0, negzero, lo, hi);
+            const unsigned keep = ((edge >> (2 * i)) & zmask) ? 0u : ~0u;
+            *reinterpret_cast<u32x4*>(planes + poff[i]) = __builtin_bit_cast(u32x4, lo) & keep;
+            *reinterpret_cast<u32x4*>(planes + (poff[i] ^ 16)) = __builtin_bit_cast(u32x4, hi) & keep;
+        };
+#pragma unroll
+        for (int g = 0; g < RING; ++g) fetch(g);
+        f32x16 acc[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            acc[i] = zero16();
+#pragma unroll
+            for (int s9 = 0; s9 < 9; ++s9) {
+                const int g = 9 * i + s9;
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0f[s9], __builtin_bit_cast(f16x8, pd[g % RING]), acc[i], 0, 0, 0);
+                if (g + RING < 9 * N) fetch(g + RING);
+            }
+            if (i > 0) put(i - 1, acc[i - 1]);
+#pragma unroll
+            for (int s9 = 0; s9 < 9; ++s9) {  // spread the previous group's post-ops and the operand refills over the multiplies
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (9 * i + s9 + RING < 9 * N) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                if (i > 0) __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        put(N - 1, acc[N - 1]);
+    };
     int cur = 0;
+#ifdef Y5_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the first patch
     for (int tile = first; tile < last; ++tile, cur ^= 1) {
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // A
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // A: the patch is complete, the other buffers are free
+        STEM_STAMP(0)
+        if (tile + 1 < last) issue(tile + 1, cur ^ 1);  // that buffer was last read by layer 0 of tile - 1
         locate(tile);
         const unsigned char* patch = smem + PATCH0 + cur * PATCH_BYTES;
         unsigned char* planes = smem + PLANES0 + cur * PLANES_BYTES;
-        // ---- layer 0 on the 17 x 33 pixels (row fy = 2 ty0 - 1 + frow, column fx = 2 tx0 - 1 + fcol of its output)
-#pragma unroll
-        for (int i = 0; i < (NT0 + NWC - 1) / NWC; ++i) {
-            const int nt = wave + NWC * i;
-            if (nt >= NT0) break;
-            const int n = nt * 32 + lr;
-            const int frow = min(n / FC, FR - 1), fcol = n - (n / FC) * FC;  // groups past the region repeat its last row (never written)
-            // patch rows 2 frow + r6, pair columns fcol .. fcol + 3 (8 image columns from 2 fcol on) of channel s % 3
-            const unsigned char* bp = patch + ((2 * frow + 3 * lh) * PDW + fcol + PCOL0) * 4;
-            f32x16 acc = zero16();
-#pragma unroll
-            for (int s = 0; s < 9; ++s) {
-                const unsigned* p = reinterpret_cast<const unsigned*>(bp + ((s % 3) * PR + s / 3) * PDW * 4);
-                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                const u32x4 u = {p[0], p[1], p[2], p[3]};
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(w0p + s * 8), __builtin_bit_cast(f16x8, u), acc, 0, 0, 0);
-            }
-            f16x8 lo, hi;
-            finish<F0>(acc, prm, C0, 16 * lh, a.slope0, negzero, lo, hi);
-            const int fy = 2 * ty0 - 1 + frow, fx = 2 * tx0 - 1 + fcol;
-            if (fy < 0 || fx < 0) {  // outside layer 0's output: layer 1's zero padding (its bottom / right windows stay inside)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) lo[e] = hi[e] = (f16)0.f;
-            }
-            if (n < FPX) {
-                const int pl = fcol & 1, np = frow * PC + (fcol >> 1);
-                *reinterpret_cast<f16x8*>(planes + plane_off(pl, np, 2 * lh)) = lo;
-                *reinterpret_cast<f16x8*>(planes + plane_off(pl, np, 2 * lh + 1)) = hi;
-            }
-        }
+        const int zmask = (ty0 == 0 ? 1 : 0) | (tx0 == 0 ? 2 : 0);  // rows / columns outside layer 0's output: layer 1's zero padding
+        STEM_STAMP(4)
+        // ---- layer 0: straight-line code per wave class, so that a group's multiplies overlap the previous group's post-ops
+        const bool full = wave + NWC * (NU - 1) < NT0;
+        if (full) layer0(std::integral_constant<int, NU>{}, patch, planes, zmask);
+        else layer0(std::integral_constant<int, NU - 1>{}, patch, planes, zmask);
+        STEM_STAMP(1)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // B: the planes are complete
+        STEM_STAMP(2)
         // ---- layer 1
         f32x16 acc = zero16();
 #pragma unroll
@@ -191,9 +247,18 @@ __global__ __launch_bounds__(NTH) void stem2_kernel(const StemArgs a) {
         f16x8 lo, hi;
         finish<F1>(acc, prm + 3 * C0, C1, mt1 * 32 + 16 * lh, a.slope1, negzero, lo, hi);
         f16* yp = a.y + ((size_t)(tb * a.Ho + ty0 + r1) * a.Wo + tx0 + c1) * a.y_ld + mt1 * 32 + 16 * lh;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile's patch pieces, issued at the top of this tile
         *reinterpret_cast<f16x8*>(yp) = lo;
         *reinterpret_cast<f16x8*>(yp + 8) = hi;
+        STEM_STAMP(3)
     }
+#ifdef Y5_STAMPS
+    if (lane == 0 && blockIdx.x < 256) {
+        unsigned long long* o = y5_stem2_stamp_buf + (blockIdx.x * 8 + wave) * 8;
+        for (int i = 0; i < 5; ++i) o[i] = st_acc[i];
+        o[7] = (unsigned long long)(last - first);
+    }
+#endif
 }
 
 int cu_count() {  // compute units of the current device (one persistent workgroup each)
@@ -223,6 +288,12 @@ int launch(const StemArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef Y5_STAMPS
+extern "C" int y5_debug_stamps_stem2(unsigned long long* dst, int n) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(y5_stem2_stamp_buf), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
+#endif
 
 // f: the Focus convolution as y5_focus_conv_f16 takes it (x = the fp16 NCHW image, y ignored); g: the 3x3 stride-2
 // convolution of its output (x ignored).

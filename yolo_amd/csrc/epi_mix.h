@@ -26,6 +26,13 @@ __device__ __forceinline__ unsigned mix_fma2(unsigned h, float s0, float s1, flo
     return t;
 }
 
+// max of two fp16 pairs (the compiler's fmax first re-rounds both operands to quiet signalling NaNs: three instructions)
+__device__ __forceinline__ unsigned pk_max2(unsigned a, unsigned b) {
+    unsigned t;
+    asm("v_pk_max_f16 %0, %1, %2" : "=v"(t) : "v"(a), "v"(b));
+    return t;
+}
+
 // Post-op parameters of the 16 channels nl..nl+15 a lane owns, of a stage with n channels (LDS -> registers).
 template <int F>
 struct Prm16 {
@@ -59,8 +66,8 @@ __device__ __forceinline__ void finish(const f32x16& acc, const Prm16<F>& q, flo
             c1 = mix_fma2(c1, q.sc[g][2], q.sc[g][3], q.sh[g][2], q.sh[g][3]);
         }
         const unsigned t0 = mix_mul2(c0, slope, negzero), t1 = mix_mul2(c1, slope, negzero);
-        o[2 * g] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(f16x2, c0), __builtin_bit_cast(f16x2, t0)));
-        o[2 * g + 1] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(f16x2, c1), __builtin_bit_cast(f16x2, t1)));
+        o[2 * g] = pk_max2(c0, t0);
+        o[2 * g + 1] = pk_max2(c1, t1);
     }
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     lo = __builtin_bit_cast(f16x8, (u32x4){o[0], o[1], o[2], o[3]});
