@@ -16,16 +16,16 @@ def one_step(root, counter):
                     rows.append((int(r['Dispatch_Id']), r['Kernel_Name'], float(r['Counter_Value'])))
     rows.sort()
     out = []
-    for first, keep in (('focus_conv_kernel', lambda n: 'nms_' not in n), ('nms_candidates_kernel', lambda n: 'nms_' in n)):
-        marks = [i for i, r in enumerate(rows) if first in r[1]]
+    for first, keep in ((('focus_conv_kernel', 'stem2_kernel'), lambda n: 'nms_' not in n), (('nms_candidates_kernel',), lambda n: 'nms_' in n)):
+        marks = [i for i, r in enumerate(rows) if any(k in r[1] for k in first)]
         if len(marks) < 2:
-            raise SystemExit('fewer than two launches of %s in %s' % (first, root))
+            raise SystemExit('fewer than two launches of %s in %s' % ('/'.join(first), root))
         out += [r for r in rows[marks[-2]:marks[-1]] if keep(r[1])]
     return out
 
 
 def family(name):
-    for key, fam in (('csp1_kernel', 'conv_csp'), ('detect_p_kernel', 'conv_detect')):
+    for key, fam in (('csp1_kernel', 'conv_csp'), ('detect_p_kernel', 'conv_detect'), ('stem2_kernel', 'conv_stem2')):
         if key in name:
             return fam
     for key in ('focus_conv', 'conv_lw', 'conv_lin3', 'conv_c64', 'conv_s2c32', 'conv_igemm', 'conv_halo', 'conv_ws1x1', 'conv3x3_ws', 'detect_decode', 'nms_', 'maxpool', 'upsample', 'copy_channels'):

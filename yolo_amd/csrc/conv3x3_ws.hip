@@ -83,8 +83,7 @@ __device__ __forceinline__ void finish_rows(const f32x16 (&acc)[BN / 32], const 
             if (MODE & 1) v += prm.bias[j * 4 + g];
             f16x4 h = __builtin_convertvector(v, f16x4);
             if (MODE & 2) h = __builtin_convertvector(__builtin_convertvector(h, f32x4) * prm.scale[j * 4 + g] + prm.shift[j * 4 + g], f16x4);
-            const f16x4 tt = __builtin_convertvector(__builtin_convertvector(h, f32x4) * a.slope, f16x4);
-            *reinterpret_cast<f16x4*>(escr + lr * EROW + nl * 2) = __builtin_elementwise_max(h, tt);
+            *reinterpret_cast<f16x4*>(escr + lr * EROW + nl * 2) = leaky4_f16(h, a.slope);
         }
     }
     constexpr int NP = 32 * CPW / 64;

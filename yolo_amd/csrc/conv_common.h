@@ -177,8 +177,7 @@ __device__ __forceinline__ f16x4 post_op4_lds_f16(f32x4 v, int nl, const float* 
         h = __builtin_convertvector(__builtin_convertvector(h, f32x4) * *reinterpret_cast<const f32x4*>(prm + bn + nl) +
                                         *reinterpret_cast<const f32x4*>(prm + 2 * bn + nl),
                                     f16x4);
-    const f16x4 t = __builtin_convertvector(__builtin_convertvector(h, f32x4) * slope, f16x4);
-    return __builtin_elementwise_max(h, t);
+    return leaky4_f16(h, slope);
 }
 template <typename ET = f16>
 __device__ __forceinline__ typename Elem<ET>::v4 post_op4_lds(f32x4 v, int nl, const float* prm, int bn, bool has_bias, bool has_scale, float slope) {
@@ -203,7 +202,6 @@ __device__ __forceinline__ f16x4 post_op4(f32x4 v, int n, const ConvArgs& a) {
         const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + n), sh = *reinterpret_cast<const f32x4*>(a.shift + n);
         h = __builtin_convertvector(__builtin_convertvector(h, f32x4) * sc + sh, f16x4);
     }
-    const f16x4 t = __builtin_convertvector(__builtin_convertvector(h, f32x4) * a.slope, f16x4);
-    return __builtin_elementwise_max(h, t);
+    return leaky4_f16(h, a.slope);
 }
 

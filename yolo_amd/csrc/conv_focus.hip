@@ -51,8 +51,7 @@ __device__ __forceinline__ void finish_tile(const f32x16 (&acc)[2][RN], const Fo
                     h = __builtin_convertvector(__builtin_convertvector(h, f32x4) * *reinterpret_cast<const f32x4*>(prm + CN + nl) +
                                                     *reinterpret_cast<const f32x4*>(prm + 2 * CN + nl),
                                                 f16x4);
-                const f16x4 tt = __builtin_convertvector(__builtin_convertvector(h, f32x4) * a.slope, f16x4);
-                *reinterpret_cast<f16x4*>(escr + lr * EROW + nl * 2) = __builtin_elementwise_max(h, tt);
+                *reinterpret_cast<f16x4*>(escr + lr * EROW + nl * 2) = leaky4_f16(h, a.slope);
             }
         }
         const int oy = oy0 + m;

@@ -164,8 +164,7 @@ __global__ __launch_bounds__(256) void conv_ws1x1_kernel(const ConvArgs a) {
                     h = __builtin_convertvector(__builtin_convertvector(h, f32x4) * *reinterpret_cast<const f32x4*>(prm + BN + pl) +
                                                     *reinterpret_cast<const f32x4*>(prm + 2 * BN + pl),
                                                 f16x4);
-                const f16x4 tt = __builtin_convertvector(__builtin_convertvector(h, f32x4) * a.slope, f16x4);
-                *reinterpret_cast<f16x4*>(escr + lr * EROW + nl * 2) = __builtin_elementwise_max(h, tt);
+                *reinterpret_cast<f16x4*>(escr + lr * EROW + nl * 2) = leaky4_f16(h, a.slope);
             }
         }
 #pragma unroll

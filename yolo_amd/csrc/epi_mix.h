@@ -6,30 +6,13 @@
 // of pixel lr in accumulator order, i.e. two whole 16-byte pieces of a [pixel][channel] row.
 __device__ __forceinline__ int perm_row(int i) { return 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3); }
 
-// Mixed-precision helpers on a pair of fp16 values packed in 32 bits: fp16 inputs widened, fp32 arithmetic with one
-// rounding, result rounded to fp16 - the conversion / multiply / conversion sequence of the layer epilogues in one
-// instruction per value.
-__device__ __forceinline__ unsigned mix_mul2(unsigned h, float s, float negzero) {  // fp16(float(h) * s)
-    unsigned t;
-    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-        : "=&v"(t)
-        : "v"(h), "v"(s), "v"(negzero));
-    return t;
-}
+// (mix_mul2 and pk_max2 come from conv_common.h.)  fp16(float(h) * s + b) on a pair of fp16 values, one rounding each:
 __device__ __forceinline__ unsigned mix_fma2(unsigned h, float s0, float s1, float b0, float b1) {  // fp16(float(h) * s + b)
     unsigned t;
     asm("v_fma_mixlo_f16 %0, %1, %2, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
         "v_fma_mixhi_f16 %0, %1, %3, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
         : "=&v"(t)
         : "v"(h), "v"(s0), "v"(s1), "v"(b0), "v"(b1));
-    return t;
-}
-
-// max of two fp16 pairs (the compiler's fmax first re-rounds both operands to quiet signalling NaNs: three instructions)
-__device__ __forceinline__ unsigned pk_max2(unsigned a, unsigned b) {
-    unsigned t;
-    asm("v_pk_max_f16 %0, %1, %2" : "=v"(t) : "v"(a), "v"(b));
     return t;
 }
 

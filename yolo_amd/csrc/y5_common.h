@@ -21,6 +21,31 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // The two 16-bit element types of the activation / weight tensors (y5_conv_desc.dtype: Y5_F16, Y5_BF16).  Both accumulate
 // in fp32; every tensor operation rounds its result to the element type once, like torch's half / bfloat16 kernels.
+// Mixed-precision helpers on a pair of fp16 values packed in 32 bits: fp16 inputs widened, fp32 arithmetic, result rounded
+// to fp16 - the conversion / multiply / conversion sequence of the layer epilogues in one instruction per value.
+static __device__ __forceinline__ unsigned mix_mul2(unsigned h, float s, float negzero) {  // fp16(float(h) * s); negzero = -0.f keeps the sign of a zero product
+    unsigned t;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(t)
+        : "v"(h), "v"(s), "v"(negzero));
+    return t;
+}
+// max of two fp16 pairs (the compiler's fmax first re-rounds both operands to quiet signalling NaNs: three instructions)
+static __device__ __forceinline__ unsigned pk_max2(unsigned a, unsigned b) {
+    unsigned t;
+    asm("v_pk_max_f16 %0, %1, %2" : "=v"(t) : "v"(a), "v"(b));
+    return t;
+}
+// LeakyReLU on four fp16 values as max(h, fp16(float(h) * slope)), slope in (0, 1] (1 = no activation)
+static __device__ __forceinline__ f16x4 leaky4_f16(f16x4 h, float slope) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 u = __builtin_bit_cast(u32x2, h);
+    const float nz = -0.f;
+    const u32x2 r = {pk_max2(u[0], mix_mul2(u[0], slope, nz)), pk_max2(u[1], mix_mul2(u[1], slope, nz))};
+    return __builtin_bit_cast(f16x4, r);
+}
+
 template <typename T>
 struct Elem;
 template <>
