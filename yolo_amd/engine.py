@@ -715,12 +715,22 @@ class Plan:
         # recorded right after the layer it reads, on the plan's side stream, so that it runs beside the rest of the
         # head instead of after it.  Off by default: measured at batch 32 it changes the forward time by < 0.5 % (the
         # chip is busy either way), and one stream keeps the plan simpler to reason about.
+        # Y5_SIDE_STREAM=2 does the same with the one-kernel levels (convolution + decode): 1.326 -> 1.313-1.323 ms
+        # (tools/exp_side_detect.py), also off.
         self.head_bufs = {}
+        self.detect_done = set()
+        self._decode_desc = None
         early = {}
-        if isinstance(head, yolo.Detect) and os.environ.get('Y5_SIDE_STREAM', '0') == '1':
+        side_mode = os.environ.get('Y5_SIDE_STREAM', '0')
+        if isinstance(head, yolo.Detect) and side_mode in ('1', '2'):
             srcs = [len(layers) - 1 + j if j < 0 else j for j in (head.f if isinstance(head.f, (list, tuple)) else [head.f])]
             if len(srcs) == head.nl and len(set(srcs)) == len(srcs):
                 early = {j: lvl for lvl, j in enumerate(srcs) if j != max(srcs)}
+                if side_mode == '2':
+                    if self.bf16 or os.environ.get('Y5_DETECT_FUSE', '1') == '0':
+                        early = {}
+                    else:
+                        self._detect_setup(head, [shapes[j][1:] for j in srcs])
         skip = set()
         for i, m in enumerate(layers):
             name = '%d.%s' % (i, type(m).__name__)
@@ -803,7 +813,10 @@ class Plan:
                     off += part.c_pad
             outs[i] = out
             if i in early:
-                self._detect_conv(head, early[i], out, side=True)
+                if side_mode == '2':
+                    self._detect_early(head, early[i], out)  # a level that does not fuse is recorded with the rest at the end
+                else:
+                    self._detect_conv(head, early[i], out, side=True)
 
     def _build_block(self, m, x):
         """Lower one building block on an NCHW fp16 input (unit tests and debugging)."""
@@ -1121,57 +1134,83 @@ class Plan:
         label = 'detect.m%d conv1x1+decode %d->%d @%dx%d v%d' % (lvl, f.c_log, cout, f.h, f.w, best)
         return label, cd, dd, best
 
-    def _detect(self, m, feats):
+    def _detect_setup(self, m, hw):
+        """Output tensors of Detect (models/yolo.py:24-46) for feature maps of sizes hw = [(h, w), ...], bound as the
+        plan's external slots 1, 2, ...; returns the function that fills a level's decode descriptor."""
         B = self.batch
         na, no = m.na, m.no
         if na > _lib.Y5_MAX_ANCHORS:
             raise Unsupported('more than %d anchors' % _lib.Y5_MAX_ANCHORS)
-        rows = [na * f.h * f.w for f in feats]
+        rows = [na * h * w for h, w in hw]
         self.z_shape = (B, sum(rows), no)
-        self.x_shapes = [(B, na, f.h, f.w, no) for f in feats]
+        self.x_shapes = [(B, na, h, w, no) for h, w in hw]
         z = torch.zeros(self.z_shape, dtype=self.dtype, device=self.device)
         xs = [torch.zeros(s, dtype=self.dtype, device=self.device) for s in self.x_shapes]
         self.keep += [z] + xs
         _lib.check(self.lib.y5_plan_bind_slot(self.handle, 1, z.data_ptr(), z.numel() * 2))
         for i, t in enumerate(xs):
             _lib.check(self.lib.y5_plan_bind_slot(self.handle, 2 + i, t.data_ptr(), t.numel() * 2))
-        row0 = 0
         anchor_grid = m.anchor_grid.detach().float().cpu().view(m.nl, na, 2)  # element-type values (the buffer follows .half() / .bfloat16())
 
-        def decode_desc(i, f, row0):
+        def decode_desc(i, f):
             d = _lib.DecodeDesc()
             d.dtype = _lib.BF16 if self.bf16 else _lib.F16
             d.x_out, d.z_out = xs[i].data_ptr(), z.data_ptr()
             d.batch, d.ny, d.nx, d.na, d.no = B, f.h, f.w, na, no
-            d.z_rows_total, d.z_row0 = self.z_shape[1], row0
+            d.z_rows_total, d.z_row0 = self.z_shape[1], sum(rows[:i])
             d.stride = float(m.stride[i])
             for a in range(na):
                 d.anchor_wh[2 * a] = float(anchor_grid[i, a, 0])
                 d.anchor_wh[2 * a + 1] = float(anchor_grid[i, a, 1])
             return d
+        self._decode_desc = decode_desc
+        return decode_desc
+
+    def _detect_early(self, m, lvl, f):
+        """Detect level lvl as one kernel on the plan's side stream, recorded right after the layer that produces its
+        feature map f; False when the one-kernel form does not take the level (nothing recorded then)."""
+        op = self._detect_fused(m, lvl, f, self._decode_desc(lvl, f))
+        if op is None:
+            return False
+        label, cd, dd, variant = op
+        _lib.check(self.lib.y5_plan_add_detect(self.handle, C.byref(cd), C.byref(dd), variant))
+        _lib.check(self.lib.y5_plan_mark_last(self.handle, _lib.PLAN_SIDE))
+        self.labels.append(label + ' (side stream)')
+        self.detect_done.add(lvl)
+        return True
+
+    def _detect(self, m, feats):
+        na, no = m.na, m.no
+        rows = [na * f.h * f.w for f in feats]
+        decode_desc = getattr(self, '_decode_desc', None) or self._detect_setup(m, [(f.h, f.w) for f in feats])
+        row0 = 0
 
         # Every level as ONE kernel (head conv with the decode as its epilogue) when all of them qualify and none was
         # already recorded on the side stream; otherwise head convs + one decode launch.
         if not self.head_bufs and not self.bf16 and os.environ.get('Y5_DETECT_FUSE', '1') != '0':
-            ops, r0 = [], 0
-            for i, f in enumerate(feats):
-                op = self._detect_fused(m, i, f, decode_desc(i, f, r0))
+            ops = []
+            todo = [i for i in range(len(feats)) if i not in self.detect_done]
+            for i in todo:
+                op = self._detect_fused(m, i, feats[i], decode_desc(i, feats[i]))
                 if op is None:
                     break
                 ops.append(op)
-                r0 += rows[i]
-            if len(ops) == len(feats):
+            if len(ops) == len(todo):
                 for label, cd, dd, variant in ops:
                     _lib.check(self.lib.y5_plan_add_detect(self.handle, C.byref(cd), C.byref(dd), variant))
                     self.labels.append(label)
+                if self.detect_done:
+                    _lib.check(self.lib.y5_plan_mark_last(self.handle, _lib.PLAN_JOIN))
                 return
+        if self.detect_done:
+            raise Unsupported('Detect levels recorded early but the rest does not fuse')
         fused = len(feats) <= _lib.Y5_MAX_LEVELS and os.environ.get('Y5_DECODE_FUSE', '1') != '0'
         levels = (_lib.DecodeDesc * len(feats))()
         for i, f in enumerate(feats):
             if i not in self.head_bufs:
                 self._detect_conv(m, i, f)
             headbuf = self.head_bufs[i]
-            d = decode_desc(i, f, row0)
+            d = decode_desc(i, f)
             d.head, d.head_ld = headbuf.ptr, headbuf.ld
             if fused:
                 C.memmove(C.byref(levels[i]), C.byref(d), C.sizeof(_lib.DecodeDesc))
