@@ -1,5 +1,6 @@
 # Round profile: kernel trace + stats of the bench command on the TUNED plan only (variant choices are made by an
-# untraced run first and replayed from Y5_TUNE_CACHE), then the two HBM counter passes.  usage: round_profile.sh TAG
+# untraced run first and replayed from Y5_TUNE_CACHE), then the two HBM counter passes and an MFMA-busy pass.
+# usage: round_profile.sh TAG
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; tag=$1
 export Y5_TUNE_CACHE=$R/gpurun_out/tune_$tag.json
@@ -7,6 +8,8 @@ timeout -k 10 300 python3 $R/bench.py --steps 20 --warmup 5 > $R/gpurun_out/benc
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$tag -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/prof_$tag.log 2>&1 &&
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch_$tag -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_fetch_$tag.log 2>&1 &&
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write_$tag -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_write_$tag.log 2>&1 &&
+timeout -s KILL 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc_mfma_$tag -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_mfma_$tag.log 2>&1 &&
+python3 $R/tools/mfma_busy.py $R/gpurun_out/pmc_mfma_$tag > $R/gpurun_out/mfma_busy_$tag.txt &&
 python3 $R/tools/hbm_traffic.py $R/gpurun_out/pmc_fetch_$tag $R/gpurun_out/pmc_write_$tag $R/gpurun_out/hbm_traffic_$tag.json > /dev/null &&
 f=$(find $R/gpurun_out/prof_$tag -name "*kernel_stats.csv" | head -1) && cp $f $R/gpurun_out/kernel_stats_$tag.csv &&
 t=$(find $R/gpurun_out/prof_$tag -name "*kernel_trace.csv" | head -1) && python3 $R/tools/trace_layers.py $t > $R/gpurun_out/trace_layers_$tag.txt && tail -5 $R/gpurun_out/trace_layers_$tag.txt
