@@ -46,3 +46,9 @@ print('%d waves, %.2f tiles each; ticks per tile, mean over waves:' % (len(s), s
 for i, n in enumerate(['barrier A', 'nine taps', 'first epilogue', 'barrier B', '1x1 + stores']):
     print('  %-16s %8.1f' % (n, (s[:, i] / s[:, 7]).mean()))
 print('  total            %8.1f' % (s[:, :5].sum(1) / s[:, 7]).mean())
+print('per wave (rows: waves 0-7; columns as above):')
+for w in range(8):
+    sw = s[w::8]
+    print('  ' + ' '.join('%8.1f' % (sw[:, i] / sw[:, 7]).mean() for i in range(5)))
+w0 = s[0::8]
+print('loader wave: waiting for its copies %.1f, issuing the next tile\'s copies %.1f ticks per tile' % ((w0[:, 5] / w0[:, 7]).mean(), (w0[:, 6] / w0[:, 7]).mean()))

@@ -33,7 +33,7 @@ struct C64Args {
 constexpr int C = 64;
 constexpr int TH = 8, TW = 16, PW = TW + 2, PH = TH + 2, HP = PH * PW;  // tile, tile + halo (180 pixels)
 constexpr int NWC = 8, NTHC = 64 * NWC, NTH = NTHC + 64;                // compute waves + the loader wave
-constexpr int ROW = C * 2;                                              // bytes per staged pixel (8 slots, slot s at s ^ ((p >> 1) & 7))
+constexpr int ROW = C * 2;                                              // bytes per staged pixel (8 slots; halo tile: slot s at s ^ ((column >> 1) & 7), 16-pixel-row tiles: s ^ ((p >> 1) & 7), the same thing there)
 constexpr int X_PIECES = (HP * ROW + 1023) / 1024, X_BYTES = X_PIECES * 1024;
 constexpr int T_BYTES = TH * TW * ROW, T_PIECES = T_BYTES / 1024;       // residual tile / first result
 constexpr int W1ROW = 9 * C * 2 + 16;                                   // weight row padded to an odd number of slots
@@ -43,6 +43,9 @@ static_assert(X0 % 1024 == 0 && RES0 % 1024 == 0, "DMA pieces land on 1 KiB boun
 static_assert(SMEM <= 160 * 1024, "fits the CU's LDS");
 
 __device__ __forceinline__ int swz(int p, int s) { return p * ROW + ((s ^ ((p >> 1) & 7)) << 4); }
+// halo tile (rows of PW = 18 pixels): the swizzle follows the COLUMN, so that the 16 lanes one ds_read_b128 pass serves (eight
+// pixels of one tile row, eight of the next, shifted by the tap) land on 16 different 16-byte bank groups for every tap
+__device__ __forceinline__ int swzx(int r, int c, int s) { return (r * PW + c) * ROW + ((s ^ ((c >> 1) & 7)) << 4); }
 
 #ifdef Y5_STAMPS
 // Diagnostic build only: per compute wave, cycles in {barrier A, taps, first epilogue, barrier B, 1x1 + store} summed over tiles
@@ -95,9 +98,9 @@ __global__ __launch_bounds__(NTH) void conv_c64_kernel(const C64Args a, const in
         int xrel[X_PIECES], xrc[X_PIECES], rrel[T_PIECES];
 #pragma unroll
         for (int d = 0; d < X_PIECES; ++d) {
-            const int slot = d * 64 + lane, hp = slot >> 3, s = (slot & 7) ^ ((hp >> 1) & 7);
-            const int r = hp / PW, c = hp - r * PW;
-            xrel[d] = (r * a.W + c) * (a.x_ld * 2) + s * 16;
+            const int slot = d * 64 + lane, hp = slot >> 3;
+            const int r = hp / PW, c = hp - r * PW, s = (slot & 7) ^ ((c >> 1) & 7);
+            xrel[d] = hp >= HP ? 0x7fffffff : (r * a.W + c) * (a.x_ld * 2) + s * 16;  // origin + this: below 2^32, at or above x_bytes
             xrc[d] = r | (c << 8) | (hp >= HP ? 1 << 16 : 0);
         }
 #pragma unroll
@@ -111,13 +114,15 @@ __global__ __launch_bounds__(NTH) void conv_c64_kernel(const C64Args a, const in
             locate(tile);
             const int base = ((tb * a.H + ty0 - 1) * a.W + tx0 - 1) * (a.x_ld * 2);
             const bool inner = ty0 > 0 && ty0 + TH < a.H && tx0 > 0 && tx0 + TW < a.W;  // the halo stays inside the image
+            if (inner) {  // no clipping: tile origin + the lane's fixed offset (slots past the tile carry an out-of-range offset)
+#pragma unroll
+                for (int d = 0; d < X_PIECES; ++d) dma16_buf(xr, (unsigned)(base + xrel[d]), (unsigned)(X0 + buf * X_BYTES + d * 1024));
+                return;
+            }
 #pragma unroll
             for (int d = 0; d < X_PIECES; ++d) {
-                bool ok = !(xrc[d] >> 16);
-                if (!inner) {
-                    const int r = xrc[d] & 255, c = (xrc[d] >> 8) & 255;
-                    ok = ok && (unsigned)(ty0 - 1 + r) < (unsigned)a.H && (unsigned)(tx0 - 1 + c) < (unsigned)a.W;
-                }
+                const int r = xrc[d] & 255, c = (xrc[d] >> 8) & 255;
+                const bool ok = !(xrc[d] >> 16) && (unsigned)(ty0 - 1 + r) < (unsigned)a.H && (unsigned)(tx0 - 1 + c) < (unsigned)a.W;
                 dma16_buf(xr, ok ? (unsigned)(base + xrel[d]) : Y5_BUF_OOB, (unsigned)(X0 + buf * X_BYTES + d * 1024));
             }
         };
@@ -133,14 +138,29 @@ __global__ __launch_bounds__(NTH) void conv_c64_kernel(const C64Args a, const in
             issue_res(first, 0);
         }
         int cur = 0;
+#ifdef Y5_STAMPS
+        unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+#endif
         for (int tile = first; tile < last; ++tile, cur ^= 1) {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // A: input and residual tiles have landed
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            C64_STAMP(5)  // waiting for the copies
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // A: input and residual tiles have landed
+            C64_STAMP(7)
             if (tile + 1 < last) {  // both buffers were last read while tile - 1 was computed
                 issue_x(tile + 1, cur ^ 1);
                 issue_res(tile + 1, cur ^ 1);
             }
+            C64_STAMP(6)  // issuing the copies
             asm volatile("s_barrier" ::: "memory");                                   // B
+            C64_STAMP(7)
         }
+#ifdef Y5_STAMPS
+        if (lane == 0 && blockIdx.x < 256) {  // the loader's figures ride in the unused fields of compute wave 0's row
+            unsigned long long* o = y5_c64_stamp_buf + (blockIdx.x * 8) * 8;
+            o[5] = st_acc[5];
+            o[6] = st_acc[6];
+        }
+#endif
         return;
     }
 
@@ -152,7 +172,7 @@ __global__ __launch_bounds__(NTH) void conv_c64_kernel(const C64Args a, const in
     for (int ks = 0; ks < C / 16; ++ks) w2f[ks] = *reinterpret_cast<const f16x8*>(a.w2 + (size_t)(mt * 32 + perm_row(lr)) * a.w2_ld + ks * 16 + lh * 8);
     int uoff[9];  // byte offset in the staged input of this lane's K-step-0 fragment per tap; K-step ks: offset ^ (ks << 5)
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) uoff[tap] = swz((r + tap / 3) * PW + c + tap % 3, lh);
+    for (int tap = 0; tap < 9; ++tap) uoff[tap] = swzx(r + tap / 3, c + tap % 3, lh);
     const unsigned char* w1p = smem + W10 + (mt * 32 + lr) * W1ROW + lh * 16;
     const int toff = swz(q, mt * 4 + 2 * lh);   // this lane's 16 channels [32 mt + 16 lh, +16) of pixel q: slots toff, toff ^ 16
     const int voff = swz(q, lh);                // first-result fragments of pixel q: K-step ks at voff ^ (ks << 5)
