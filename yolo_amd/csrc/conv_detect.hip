@@ -1,15 +1,17 @@
 // One Detect level - the head's 1x1 convolution (bias, no activation) with the box decode as its epilogue - as a
-// PERSISTENT kernel for the head of 128 input channels (models/yolo.py:24-46 on the finest pyramid level, where most
-// of Detect's output is written).
+// PERSISTENT kernel for heads of 128 or 256 input channels (models/yolo.py:24-46; the finest pyramid level, where
+// most of Detect's output is written, has 128 in yolov5s).
 //
 // The GEMM of a level is tiny per pixel (K <= 256, 255 outputs) and its traffic is nearly all output (x_i and z, 2 x 255
 // halfs per pixel), so the kernel is organised around keeping stores in flight: one workgroup per CU walks a contiguous run
 // of 64-pixel tiles; each of its 8 compute waves owns 32 output channels and keeps their weights in registers for the
 // whole kernel (no weight traffic after the first tile); a ninth wave copies the next tile's input pixels global -> LDS
-// by DMA while the current tile is decoded and stored.  The decode runs in the GEMM's epilogue on the accumulator
+// by DMA while the current tile is decoded and stored (128 channels; with 256 the weights need more registers than
+// a nine-wave workgroup leaves a wave, so there the eight compute waves share the copy, four 1 KiB pieces each, and
+// wait for them right before their own copy out, half a tile after issuing them).  The decode runs in the GEMM's epilogue on the accumulator
 // registers (every lane busy, no index arithmetic per element), writes raw and decoded values into two LDS images laid
 // out like the output runs, and the copy out is 16-byte pieces.  The waves never wait for their own global stores:
-// barriers are LDS-only, and the only vmcnt wait is the loader's, whose only memory operations are the copies.
+// barriers are LDS-only, and a vmcnt wait only ever covers input copies.
 #include <atomic>
 
 #include "y5_common.h"
@@ -28,7 +30,7 @@ struct DetArgs {
     FastDiv div_tpi, div_nx, div_no;
 };
 
-constexpr int NWC = 8, NTHC = 64 * NWC, NTH = NTHC + 64;  // compute waves (threads 0..511) + the loader wave
+constexpr int NWC = 8, NTHC = 64 * NWC;  // compute waves (threads 0..511); with a loader wave 64 more threads
 
 template <int KS>  // the head has 16 * KS input channels
 struct DetCfg {
@@ -45,8 +47,8 @@ struct DetCfg {
 
 __device__ __forceinline__ int perm_row(int i) { return 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3); }  // see conv_csp.hip
 
-template <int KS>
-__global__ __launch_bounds__(NTH) void detect_p_kernel(const DetArgs a, const DecodeArgs dec) {
+template <int KS, bool LW>  // LW: a ninth wave issues the input copies
+__global__ __launch_bounds__(NTHC + (LW ? 64 : 0)) void detect_p_kernel(const DetArgs a, const DecodeArgs dec) {
     typedef DetCfg<KS> Cfg;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int t = threadIdx.x, lane = t & 63, lr = lane & 31, lh = lane >> 5;
@@ -54,26 +56,29 @@ __global__ __launch_bounds__(NTH) void detect_p_kernel(const DetArgs a, const De
     const int nwg = gridDim.x, g = xcd_remap(blockIdx.x, nwg);
     const int first = (int)((long long)g * a.ntiles / nwg), last = (int)((long long)(g + 1) * a.ntiles / nwg);
 
-    if (wave == NWC) {
-        // ------------------------------------------------------------------ loader wave
-        const i32x4 xr = make_buf(a.x, a.x_bytes);
-        auto issue = [&](int tile) {
-            const int b = (int)fdiv((unsigned)tile, a.div_tpi);
-            const int pix0 = (tile - b * a.tiles_per_image) * TP;
-            const int np = min(TP, a.npix - pix0);
-            const unsigned base = (unsigned)((b * a.npix + pix0) * a.x_ld * 2);
+    // copies of a tile's input pixels: pieces d0, d0 + dstep, ... (all of them in the loader wave, every eighth otherwise)
+    const i32x4 xr = make_buf(a.x, a.x_bytes);
+    auto issue = [&](int tile, int d0, int dstep) {
+        const int b = (int)fdiv((unsigned)tile, a.div_tpi);
+        const int pix0 = (tile - b * a.tiles_per_image) * TP;
+        const int np = min(TP, a.npix - pix0);
+        const unsigned base = (unsigned)((b * a.npix + pix0) * a.x_ld * 2);
 #pragma unroll
-            for (int d = 0; d < Cfg::PIECES; ++d) {
-                const int slot = d * 64 + lane, px = slot / Cfg::SLOTS, sp = slot % Cfg::SLOTS;
-                const int s = sp ^ (px & 15);
-                dma16_buf(xr, px < np ? base + (unsigned)(px * a.x_ld * 2 + s * 16) : Y5_BUF_OOB, (unsigned)(d * 1024));
-            }
-        };
-        if (first < last) issue(first);
+        for (int j = 0; j < Cfg::PIECES; ++j) {
+            const int d = d0 + j * dstep;
+            if (d >= Cfg::PIECES) break;
+            const int slot = d * 64 + lane, px = slot / Cfg::SLOTS, sp = slot % Cfg::SLOTS;
+            const int s = sp ^ (px & 15);
+            dma16_buf(xr, px < np ? base + (unsigned)(px * a.x_ld * 2 + s * 16) : Y5_BUF_OOB, (unsigned)(d * 1024));
+        }
+    };
+    if (LW && wave == NWC) {
+        // ------------------------------------------------------------------ loader wave
+        if (first < last) issue(first, 0, 1);
         for (int tile = first; tile < last; ++tile) {
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // A: the tile's pixels have landed
             asm volatile("s_barrier" ::: "memory");                        // B: the products have read them
-            if (tile + 1 < last) issue(tile + 1);
+            if (tile + 1 < last) issue(tile + 1, 0, 1);
             asm volatile("s_barrier" ::: "memory");                        // C
             asm volatile("s_barrier" ::: "memory");                        // D
         }
@@ -99,6 +104,10 @@ __global__ __launch_bounds__(NTH) void detect_p_kernel(const DetArgs a, const De
     f16* decs = reinterpret_cast<f16*>(smem + Cfg::DEC0);
     f16* const x_out = dec.x_out;
     f16* const z_out = dec.z_out;
+    if (!LW) {
+        if (first < last) issue(first, wave, NWC);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the first tile
+    }
     for (int tile = first; tile < last; ++tile) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // A: input landed; the previous tile's copy out is done
         const int b = (int)fdiv((unsigned)tile, a.div_tpi);
@@ -116,7 +125,10 @@ __global__ __launch_bounds__(NTH) void detect_p_kernel(const DetArgs a, const De
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], *reinterpret_cast<const f16x8*>(smem + px * Cfg::XROW + (((2 * ks + lh) ^ (px & 15)) << 4)), acc, 0, 0, 0);
-            if (nt == 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // B: the loader may overwrite the input
+            if (nt == 1) {
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // B: the input may be overwritten
+                if (!LW && tile + 1 < last) issue(tile + 1, wave, NWC);
+            }
             const int row = px * no;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -145,6 +157,7 @@ __global__ __launch_bounds__(NTH) void detect_p_kernel(const DetArgs a, const De
             decs[off] = decode_one<f16>(raws[off], o, (float)gx, (float)gy, dec.anchor_wh[2 * an], dec.anchor_wh[2 * an + 1], dec.stride);
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // D
+        if (!LW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile's pieces, issued after B; older than any store still in flight
         // copy out: per anchor np * no consecutive halfs of x_i and of z, starting on 16-byte boundaries
         const int run = np * no, nwin = run >> 3;
         const int npix_img = a.npix;
@@ -177,17 +190,17 @@ int cu_count() {  // compute units of the current device (one persistent workgro
     return n;
 }
 
-template <int KS>
+template <int KS, bool LW>
 int launch(const DetArgs& a, const DecodeArgs& dec, hipStream_t s) {
     typedef DetCfg<KS> Cfg;
     static std::atomic<unsigned long long> attr_set{0};
     const unsigned long long bit = 1ull << y5_current_device();
     if (!(attr_set.load() & bit)) {
-        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(detect_p_kernel<KS>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(detect_p_kernel<KS, LW>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
         attr_set.fetch_or(bit);
     }
     const int cus = cu_count();
-    hipLaunchKernelGGL(detect_p_kernel<KS>, dim3((unsigned)(a.ntiles < cus ? a.ntiles : cus)), dim3(NTH), (size_t)Cfg::SMEM, s, a, dec);
+    hipLaunchKernelGGL((detect_p_kernel<KS, LW>), dim3((unsigned)(a.ntiles < cus ? a.ntiles : cus)), dim3(NTHC + (LW ? 64 : 0)), (size_t)Cfg::SMEM, s, a, dec);
     Y5_LAUNCH_CHECK("detect_p_kernel");
     return Y5_OK;
 }
@@ -197,7 +210,7 @@ int launch(const DetArgs& a, const DecodeArgs& dec, hipStream_t s) {
 // The arguments were validated by y5_launch_detect.  Returns 0 when the level is outside what this kernel is compiled for
 // (then *rc is untouched), 1 after a launch attempt with its status in *rc.
 int y5_try_detect_persistent(const y5_conv_desc& c, const y5_decode_desc& d, hipStream_t s, int* rc) {
-    if (c.cin != 128) return 0;  // 256 channels of weights per wave do not fit the register file of a nine-wave workgroup
+    if (c.cin != 128 && c.cin != 256) return 0;  // 512 channels: 128 weight registers per lane, spills
     DecodeArgs dec;
     size_t lds_bytes = 0;
     bool vec = false;
@@ -219,6 +232,6 @@ int y5_try_detect_persistent(const y5_conv_desc& c, const y5_decode_desc& d, hip
     a.div_no = make_fastdiv((unsigned)d.no);
     if ((TP * d.no) % 8) return 0;  // per-anchor blocks of the staged tiles start on 16-byte boundaries
     if (d.no < 16) return 0;        // a lane's 16 channels cross at most one anchor boundary
-    *rc = launch<8>(a, dec, s);
+    *rc = c.cin == 128 ? launch<8, true>(a, dec, s) : launch<16, false>(a, dec, s);
     return 1;
 }
