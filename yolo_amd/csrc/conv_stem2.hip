@@ -36,7 +36,7 @@ struct StemArgs {
 constexpr int C0 = 32, C1 = 64;
 constexpr int TH = 8, TW = 16;                                   // tile of layer 1's output
 constexpr int FR = 2 * TH + 1, FC = 2 * TW + 1, FPX = FR * FC;   // layer 0 pixels a tile needs: 17 x 33
-constexpr int PC = (FC + 1) / 2;                                 // columns per plane (17)
+constexpr int PC = (FC + 1) / 2 + 1;                             // pixels per plane row: 17 columns + 1 (see plane_off)
 constexpr int NT0 = (FPX + 31) / 32;                             // 32-pixel groups of them (18)
 // image patch per channel: 38 rows of 40 pixel pairs = ten 16-byte slots, from image column 4 tx0 - 8 on (16-byte aligned;
 // the windows use columns 4 tx0 - 4 .. 4 tx0 + 65, i.e. pairs 2 .. 36): every slot lies entirely inside or outside the image
@@ -44,7 +44,7 @@ constexpr int PR = 2 * FR + 4, PDW = 40, PSLOTS = PDW / 4, PCOL0 = 2;
 constexpr int PATCH_PIECES = (3 * PR * PSLOTS + 63) / 64, PATCH_BYTES = PATCH_PIECES * 1024;
 constexpr int W0ROW = 152;                                       // halfs per layer-0 weight row in LDS: 18 k-groups of 8 + 8 pad (19 slots: conflict-free)
 constexpr int ROW = C0 * 2;                                      // bytes per layer-0 pixel in the planes
-constexpr int PLANES_USED = 2 * FR * PC * ROW;                   // 36 992
+constexpr int PLANES_USED = 2 * FR * PC * ROW;                   // 39 168
 constexpr int PLANES_BYTES = PLANES_USED + 64 * 32;              // + a 32-byte slot per lane for the lanes past the region
 constexpr int NWC = 8, NTH = 64 * NWC;
 constexpr int MYP = (PATCH_PIECES + NWC - 1) / NWC;              // patch pieces a wave copies (piece d belongs to wave d % 8)
@@ -52,8 +52,12 @@ constexpr int PATCH0 = 0, PLANES0 = 2 * PATCH_BYTES, PRM0 = PLANES0 + 2 * PLANES
 constexpr int SMEM = W00 + C0 * W0ROW * 2;
 static_assert(PLANES0 % 16 == 0 && PRM0 % 16 == 0 && W00 % 16 == 0 && SMEM <= 160 * 1024, "LDS layout");
 
-// layer-0 pixel n = row * PC + j of plane pl (0: odd columns of the needed region, i.e. columns 2 tx0 - 1, + 1, ...; 1: even)
-__device__ __forceinline__ int plane_off(int pl, int n, int s) { return (pl * FR * PC + n) * ROW + ((s ^ ((n >> 2) & 3)) << 4); }
+// 16-byte slot s of layer-0 pixel (row, j) of plane pl (0: odd columns of the needed region, i.e. columns 2 tx0 - 1, + 1, ...;
+// 1: even).  Layer 1 reads, per ds_read_b128 pass, eight pixels of one plane row and eight of the row two below, shifted by
+// the tap: with a row pitch of 18 pixels (two rows = a multiple of four pixels = of 256 bytes) and the swizzle following the
+// COLUMN, the 16 lanes land on 16 different bank groups for every tap (pitch 17 and a swizzle on the linear index: 2-way
+// conflicts on every read)
+__device__ __forceinline__ int plane_off(int pl, int row, int j, int s) { return ((pl * FR + row) * PC + j) * ROW + ((s ^ ((j >> 2) & 3)) << 4); }
 
 #ifdef Y5_STAMPS
 // Diagnostic build only: per compute wave, cycles in {barrier A, layer 0, barrier B, layer 1 + store} summed over tiles
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(NTH) void stem2_kernel(const StemArgs a) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int row = 2 * r1 + tap / 3, dx = tap % 3;
-        uoff[tap] = dx == 1 ? plane_off(1, row * PC + c1, lh) : plane_off(0, row * PC + c1 + (dx == 2 ? 1 : 0), lh);
+        uoff[tap] = dx == 1 ? plane_off(1, row, c1, lh) : plane_off(0, row, c1 + (dx == 2 ? 1 : 0), lh);
     }
     // layer 0: this wave's 32-pixel groups wave, wave + 8, (wave + 16) of the 17 x 33 region; pixel n = 32 group + lr sits
     // in row frow, column fcol (row fy = 2 ty0 - 1 + frow, column fx = 2 tx0 - 1 + fcol of layer 0's output)
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(NTH) void stem2_kernel(const StemArgs a) {
         const int frow = min(n / FC, FR - 1), fcol = n - (n / FC) * FC;  // lanes past the region repeat its last row (never written)
         // patch rows 2 frow + r6, pair columns fcol .. fcol + 3 (8 image columns from 2 fcol on)
         boff[i] = ((2 * frow + 3 * lh) * PDW + fcol + PCOL0) * 4;
-        poff[i] = n < FPX ? plane_off(fcol & 1, frow * PC + (fcol >> 1), 2 * lh) : PLANES_USED + lane * 32;  // past the region: a slot nobody reads
+        poff[i] = n < FPX ? plane_off(fcol & 1, frow, fcol >> 1, 2 * lh) : PLANES_USED + lane * 32;  // past the region: a slot nobody reads
         edge |= ((frow == 0 ? 1 : 0) | (fcol == 0 ? 2 : 0)) << (2 * i);
     }
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(NTH) void stem2_kernel(const StemArgs a) {
         constexpr int N = decltype(nu_c)::value;
         // the image words of multiply g = 9 group + s9 (channel s9 % 3, window rows s9 / 3 in lanes 0-31 and 3 + s9 / 3 in lanes
         // 32-63) sit in slot g % RING; a slot is refilled for multiply g + RING right after multiply g has read it
-        constexpr int RING = 4;
+        constexpr int RING = 3;
         u32x4 pd[RING];
         auto fetch = [&](int g) {
             const int i = g / 9, s9 = g % 9;
