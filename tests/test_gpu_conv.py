@@ -198,6 +198,16 @@ VARIANT_SHAPES = [
     (32, 64, 64, 80, 80, 3, 1),
     (16, 128, 200, 56, 72, 1, 1),
     (24, 32, 48, 96, 64, 3, 2),
+    # the persistent 64 -> 128 stride-2 kernel's shape class (output height % 4 == 0, width % 16 == 0): two tiles; 432 tiles
+    (2, 64, 128, 8, 32, 3, 2),
+    (9, 64, 128, 48, 64, 3, 2),
+    # the persistent 1x1 kernel's channel classes; pixel counts that are not whole tiles, fewer and more tiles than workgroups
+    (3, 256, 256, 21, 23, 1, 1),
+    (32, 256, 256, 40, 40, 1, 1),
+    (2, 128, 128, 37, 5, 1, 1),
+    (32, 128, 128, 40, 40, 1, 1),
+    (5, 256, 128, 33, 31, 1, 1),
+    (5, 128, 256, 33, 31, 1, 1),
 ]
 
 
@@ -235,6 +245,12 @@ def test_every_kernel_variant_that_takes_the_shape(dev, shape):
     assert taken >= 10
     if (Ci, Co, k, s) == (32, 64, 3, 2) and (H // 2) % 8 == 0 and (W // 2) % 16 == 0:
         assert run_conv(dev, x, w, bias=bias, slope=0.1, stride=s, variant=_lib.lib().y5_conv_num_variants()) is not None, 'the persistent stride-2 kernel takes this shape'
+    if k == 1 and Ci in (128, 256) and Co in (128, 256):
+        nv = _lib.lib().y5_conv_num_variants()
+        assert run_conv(dev, x, w, bias=bias, slope=0.1, stride=s, variant=nv - 3) is not None, 'the persistent 1x1 kernel takes this shape'
+        assert (run_conv(dev, x, w, bias=bias, slope=0.1, stride=s, variant=nv - 4) is not None) == ((Ci, Co) != (256, 128))
+    if (Ci, Co, k, s) == (64, 128, 3, 2) and (H // 2) % 4 == 0 and (W // 2) % 16 == 0:
+        assert run_conv(dev, x, w, bias=bias, slope=0.1, stride=s, variant=_lib.lib().y5_conv_num_variants() - 2) is not None, 'the persistent 64-channel stride-2 kernel takes this shape'
 
 
 @pytest.mark.parametrize('shape', [(2, 64, 96, 32), (3, 42, 74, 32), (1, 128, 66, 48), (2, 36, 130, 80), (1, 640, 640, 32)],

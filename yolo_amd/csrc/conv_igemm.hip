@@ -545,10 +545,22 @@ int y5_launch_conv(const y5_conv_desc& d, hipStream_t s, const Y5ConvStats* st) 
         Y5_REQUIRE((reinterpret_cast<uintptr_t>(st->partials) & 3) == 0, "conv: misaligned statistics pointer");
         if (d.variant > kNumIgemm) return y5_fail(Y5_EINVAL, "conv: variant %d does not accumulate statistics (variants 1..%d do)", d.variant, kNumIgemm);
     }
-    if (d.variant > kNumIgemm + kNumHalo + kNumWs + kNumWs3 + y5_conv_lw_count() + y5_conv_lin_count()) {
+    // the persistent kernels for single shape classes come last: 1x1 (conv_p1x1.hip), 3x3 stride 2 from 64 and from 32 channels
+    const int kBase = kNumIgemm + kNumHalo + kNumWs + kNumWs3 + y5_conv_lw_count() + y5_conv_lin_count();
+    if (d.variant > kBase + y5_conv_p1x1_count() + y5_conv_s2c64_count()) {
         int rc = Y5_OK;
-        if (y5_try_conv_s2c32(d, s, d.variant - kNumIgemm - kNumHalo - kNumWs - kNumWs3 - y5_conv_lw_count() - y5_conv_lin_count(), &rc)) return rc;
+        if (y5_try_conv_s2c32(d, s, d.variant - kBase - y5_conv_p1x1_count() - y5_conv_s2c64_count(), &rc)) return rc;
         return y5_fail(Y5_EINVAL, "conv: the persistent stride-2 variant %d takes 3x3 stride 2, 32 -> 64 channels, output height %% 8 == 0 and width %% 16 == 0", d.variant);
+    }
+    if (d.variant > kBase + y5_conv_p1x1_count()) {
+        int rc = Y5_OK;
+        if (y5_try_conv_s2c64(d, s, &rc)) return rc;
+        return y5_fail(Y5_EINVAL, "conv: the persistent stride-2 variant %d takes 3x3 stride 2, 64 -> 128 channels, output height %% 4 == 0 and width %% 16 == 0", d.variant);
+    }
+    if (d.variant > kBase) {
+        int rc = Y5_OK;
+        if (y5_try_conv_p1x1(d, s, d.variant - kBase, &rc)) return rc;
+        return y5_fail(Y5_EINVAL, "conv: the persistent 1x1 variant %d takes 1x1 stride 1 with 128 or 256 input and output channels, no residual", d.variant);
     }
     if (d.variant > kNumIgemm + kNumHalo + kNumWs + kNumWs3 + y5_conv_lw_count()) {
         int rc = Y5_OK;
@@ -650,7 +662,7 @@ int y5_launch_conv(const y5_conv_desc& d, hipStream_t s, const Y5ConvStats* st) 
     return table[v].launch(a, d.ksize, direct, s);
 }
 
-int y5_conv_variant_count() { return kNumIgemm + kNumHalo + kNumWs + kNumWs3 + y5_conv_lw_count() + y5_conv_lin_count() + y5_conv_s2c32_count(); }
+int y5_conv_variant_count() { return kNumIgemm + kNumHalo + kNumWs + kNumWs3 + y5_conv_lw_count() + y5_conv_lin_count() + y5_conv_p1x1_count() + y5_conv_s2c64_count() + y5_conv_s2c32_count(); }
 
 int y5_conv_cat2_variant_count() { return kNumCat2; }
 int y5_conv_bf16_variant_count() { return kNumBf; }

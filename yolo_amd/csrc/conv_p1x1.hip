@@ -1,0 +1,208 @@
+// 1x1 stride-1 convolution with 128 or 256 input channels and 128 or 256 output channels as a PERSISTENT kernel: the
+// BottleneckCSP cv1 | cv2 and cv4 layers and the Bottleneck cv1 layers of the 40x40 stages (Conv.forward,
+// models/common.py:26; BottleneckCSP.forward :59-62).  These layers move 26 - 52 MB for 1.7 - 6.7 GFLOP at batch 32: they
+// are bound by memory, and a tiled GEMM kernel spends as long filling and draining its ring per tile as multiplying.
+//
+// One workgroup per CU walks a contiguous run of pixel tiles.  Eight waves - (output-channel blocks of 32) x (pixel groups)
+// - keep the weights of their 32 channels in registers for the whole kernel (64 registers at 256 input channels), so
+// after the first tile the only traffic is pixels in, pixels out.  Every wave copies four 1 KiB pieces of a tile's
+// [pixel][channel] rows global -> LDS by DMA, two tiles ahead (three buffers); 16-byte slot s of pixel p is stored at
+// s ^ (p & 15), which makes the fragment reads conflict-free.  One LDS-only barrier per tile; the one vmcnt wait per tile
+// - for the copies issued a whole tile earlier, with the copies issued at the top of this tile allowed to stay in flight -
+// sits right before the tile's stores, which go out from registers.
+#include <atomic>
+
+#include "y5_common.h"
+
+namespace {
+
+#include "conv_common.h"
+#include "epi_mix.h"
+
+struct P1Args {
+    const f16* x;
+    f16* y;
+    const f16* w;
+    const float *bias, *scale, *shift;
+    int w_ld, x_ld, y_ld, x_bytes;
+    int npix, ntiles;
+    float slope;
+};
+
+constexpr int NWC = 8, NTH = 64 * NWC, NBUF = 3;
+
+template <int KS, int NCW, int NT>  // 16 KS input channels, 32 NCW output channels, NT 32-pixel groups per wave and tile
+struct P1Cfg {
+    static constexpr int CI = 16 * KS, CO = 32 * NCW, PXW = NWC / NCW;
+    static constexpr int TP = 32 * NT * PXW;                 // pixels per tile
+    static constexpr int SLOTS = 2 * KS, XROW = SLOTS * 16;  // a staged pixel
+    static_assert(SLOTS >= 16 && (SLOTS & (SLOTS - 1)) == 0, "the swizzle needs rows of 16 slots or more");
+    static constexpr int X_BYTES = TP * XROW, PIECES = X_BYTES / 1024, MYP = PIECES / NWC;
+    static_assert(MYP * NWC * 1024 == X_BYTES, "every wave copies the same number of whole pieces");
+    static constexpr int PRM0 = NBUF * X_BYTES, SMEM = PRM0 + 3 * CO * 4;
+    static_assert(SMEM <= 160 * 1024, "fits the CU's LDS");
+};
+
+template <int KS, int NCW, int NT, int F>
+__global__ __launch_bounds__(NTH) void conv_p1x1_kernel(const P1Args a) {
+    typedef P1Cfg<KS, NCW, NT> Cfg;
+    constexpr int MYP = Cfg::MYP;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int t = threadIdx.x, lane = t & 63, lr = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int nwg = gridDim.x, g = xcd_remap(blockIdx.x, nwg);
+    const int first = (int)((long long)g * a.ntiles / nwg), last = (int)((long long)(g + 1) * a.ntiles / nwg);
+
+    float* prm = reinterpret_cast<float*>(smem + Cfg::PRM0);
+    for (int i = t; i < Cfg::CO; i += NTH) {
+        prm[i] = a.bias ? a.bias[i] : 0.f;
+        prm[Cfg::CO + i] = a.scale ? a.scale[i] : 1.f;
+        prm[2 * Cfg::CO + i] = a.scale ? a.shift[i] : 0.f;
+    }
+
+    const int mt = wave % NCW, pg = wave / NCW;  // output channels [32 mt, +32); pixels [32 NT pg, +32 NT) of the tile
+    f16x8 wf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) wf[ks] = *reinterpret_cast<const f16x8*>(a.w + (size_t)(mt * 32 + perm_row(lr)) * a.w_ld + ks * 16 + lh * 8);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // from here on the only loads in flight are the copies counted below
+
+    // ---------------------------------------------------------------------- the copies: wave w issues pieces w, w + 8, ...
+    const i32x4 xr = make_buf(a.x, a.x_bytes);
+    int rel[MYP], cpx[MYP];  // per-lane constants: byte offset from the tile's first pixel, pixel within the tile
+#pragma unroll
+    for (int j = 0; j < MYP; ++j) {
+        const int slot = (wave + NWC * j) * 64 + lane, px = slot / Cfg::SLOTS, sp = slot % Cfg::SLOTS;
+        cpx[j] = px;
+        rel[j] = px * (a.x_ld * 2) + ((sp ^ (px & 15)) << 4);
+    }
+    auto issue = [&](int tile, int buf) {
+        const int pix0 = tile * Cfg::TP, left = a.npix - pix0;
+        const int base = pix0 * (a.x_ld * 2);
+#pragma unroll
+        for (int j = 0; j < MYP; ++j)
+            dma16_buf(xr, cpx[j] < left ? (unsigned)(base + rel[j]) : Y5_BUF_OOB, (unsigned)(buf * Cfg::X_BYTES + (wave + NWC * j) * 1024));
+    };
+
+    int uoff[NT];  // byte offset of this lane's K-step-0 fragment per pixel group; K-step ks: offset ^ (ks << 5)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int px = (pg * NT + nt) * 32 + lr;
+        uoff[nt] = px * Cfg::XROW + ((lh ^ (px & 15)) << 4);
+    }
+    float negzero;
+    asm volatile("v_mov_b32 %0, 0x80000000" : "=v"(negzero));
+
+    // two tiles ahead: when tile i's pieces are waited for, those of tile i + 1 (the newest MYP) may still be in flight
+    if (first < last) issue(first, 0);
+    if (first + 1 < last) {
+        issue(first + 1, 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MYP) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    Prm16<F> q;
+    bool have_prm = false;
+    int buf = 0;
+    for (int tile = first; tile < last; ++tile) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave's pieces of this tile have landed; tile - 1 is read
+        if (tile + 2 < last) issue(tile + 2, buf == 0 ? NBUF - 1 : buf - 1);  // the buffer that held tile - 1
+        if (!have_prm) {  // the parameters were staged by all threads before the first barrier
+            q.load(prm, Cfg::CO, mt * 32 + 16 * lh);
+            have_prm = true;
+        }
+        const unsigned char* X = smem + buf * Cfg::X_BYTES;
+        f16x8 lo[NT], hi[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x16 acc = zero16();
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], *reinterpret_cast<const f16x8*>(X + (uoff[nt] ^ (ks << 5))), acc, 0, 0, 0);
+            finish<F>(acc, q, a.slope, negzero, lo[nt], hi[nt]);
+        }
+        // the next tile's pieces (issued a whole tile ago) must have landed before the next barrier; the pieces issued at the
+        // top of this tile are younger and may stay in flight, this tile's stores are issued after the wait
+        if (tile + 2 < last)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MYP) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int pix0 = tile * Cfg::TP;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int pix = pix0 + (pg * NT + nt) * 32 + lr;
+            if (pix < a.npix) {
+                f16* yp = a.y + (size_t)pix * a.y_ld + mt * 32 + 16 * lh;
+                *reinterpret_cast<f16x8*>(yp) = lo[nt];
+                *reinterpret_cast<f16x8*>(yp + 8) = hi[nt];
+            }
+        }
+        buf = buf == NBUF - 1 ? 0 : buf + 1;
+    }
+}
+
+int cu_count() {  // compute units of the current device (one persistent workgroup each)
+    static std::atomic<int> cached[64];
+    const int dev = y5_current_device();
+    int n = cached[dev].load();
+    if (n == 0) {
+        int real = 0;
+        if (hipGetDevice(&real) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, real) != hipSuccess || n <= 0) n = 256;
+        cached[dev].store(n);
+    }
+    return n;
+}
+
+template <int KS, int NCW, int NT, int F>
+int launch_f(P1Args& a, hipStream_t s) {
+    typedef P1Cfg<KS, NCW, NT> Cfg;
+    static std::atomic<unsigned long long> attr_set{0};
+    const unsigned long long bit = 1ull << y5_current_device();
+    if (!(attr_set.load() & bit)) {
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p1x1_kernel<KS, NCW, NT, F>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+        attr_set.fetch_or(bit);
+    }
+    a.ntiles = (a.npix + Cfg::TP - 1) / Cfg::TP;
+    const int cus = cu_count();
+    hipLaunchKernelGGL((conv_p1x1_kernel<KS, NCW, NT, F>), dim3((unsigned)(a.ntiles < cus ? a.ntiles : cus)), dim3(NTH), (size_t)Cfg::SMEM, s, a);
+    Y5_LAUNCH_CHECK("conv_p1x1_kernel");
+    return Y5_OK;
+}
+
+template <int KS, int NCW, int NT>
+int launch(P1Args& a, int f, hipStream_t s) {
+    return f == 0 ? launch_f<KS, NCW, NT, 0>(a, s) : f == 1 ? launch_f<KS, NCW, NT, 1>(a, s) : f == 2 ? launch_f<KS, NCW, NT, 2>(a, s) : launch_f<KS, NCW, NT, 3>(a, s);
+}
+
+}  // namespace
+
+int y5_conv_p1x1_count() { return 2; }
+
+// which = 1 (two 32-pixel groups per wave and tile) or 2 (one: tiles half as large, twice as many).  Returns 0 when the
+// convolution is outside what this kernel is compiled for (then *rc is untouched), 1 after a launch attempt with its
+// status in *rc.  d was validated by y5_launch_conv.
+int y5_try_conv_p1x1(const y5_conv_desc& d, hipStream_t s, int which, int* rc) {
+    if (which < 1 || which > 2 || d.ksize != 1 || d.stride != 1 || d.pad != 0 || d.res) return 0;
+    if ((d.cin != 128 && d.cin != 256) || (d.cout != 128 && d.cout != 256)) return 0;
+    if (d.w_rows < d.cout || d.kpad < d.cin) return 0;
+    const long long npix = (long long)d.batch * d.h * d.w_in;
+    const long long xb = ((npix - 1) * d.x_ld + d.cin) * 2;
+    if (npix <= 0 || npix >= 0x7fffffffLL || xb >= 0x7fffffffLL) return 0;
+    P1Args a{};
+    a.x = static_cast<const f16*>(d.x);
+    a.y = static_cast<f16*>(d.y);
+    a.w = static_cast<const f16*>(d.w);
+    a.bias = d.bias; a.scale = d.scale; a.shift = d.shift;
+    a.w_ld = d.kpad; a.x_ld = d.x_ld; a.y_ld = d.y_ld; a.x_bytes = (int)xb;
+    a.npix = (int)npix;
+    a.slope = d.act == Y5_ACT_LEAKY ? d.slope : 1.f;
+    const int f = (d.bias ? 1 : 0) | (d.scale ? 2 : 0);
+    if (d.cin == 256 && d.cout == 256) *rc = which == 1 ? launch<16, 8, 2>(a, f, s) : launch<16, 8, 1>(a, f, s);
+    else if (d.cin == 128 && d.cout == 128) *rc = which == 1 ? launch<8, 4, 2>(a, f, s) : launch<8, 4, 1>(a, f, s);
+    else if (d.cin == 256 && d.cout == 128) {
+        if (which == 1) return 0;  // three 64 KiB buffers do not fit
+        *rc = launch<16, 4, 1>(a, f, s);
+    } else {
+        *rc = which == 1 ? launch<8, 8, 2>(a, f, s) : launch<8, 8, 1>(a, f, s);
+    }
+    return 1;
+}
