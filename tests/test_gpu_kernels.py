@@ -50,7 +50,9 @@ def test_maxpool_and_cascade(dev, k):
 
 
 @pytest.mark.parametrize('c,h,w,levels,k', [(32, 20, 20, 3, 5), (24, 20, 14, 3, 5), (16, 33, 40, 2, 3), (8, 45, 45, 3, 5),
-                                            (256, 20, 20, 3, 5), (16, 7, 5, 4, 3)])
+                                            (256, 20, 20, 3, 5), (16, 7, 5, 4, 3),
+                                            # the in-register cascade (k = 5, <= 3 levels, planes up to 20 x 20, c % 32 == 0)
+                                            (64, 16, 20, 3, 5), (32, 20, 13, 2, 5), (32, 5, 3, 1, 5), (96, 1, 20, 3, 5)])
 def test_maxpool_cascade_shapes(dev, c, h, w, levels, k):
     """Two vectors per workgroup (c % 16 == 0), one vector, and planes too large for the three-plane kernels."""
     lib = _lib.lib()

@@ -213,6 +213,79 @@ __global__ __launch_bounds__(kThreads) void maxpool_cascade_sep_kernel(const f16
     }
 }
 
+// The 5 x 5 cascade (SPP's 5 / 9 / 13 pools) for planes of up to MAXD x MAXD pixels, in REGISTERS: a thread owns one row
+// (then one column) of one 8-channel vector.  The 9-wide window at x is the union of the 5-wide windows at x - 2 and x + 2,
+// the 13-wide one the union of the 9-wide windows at x - 2 and x + 2, so every level costs one max per element after the
+// first; positions outside the plane hold -inf (what max pooling pads with).  Row maxes of all levels go through LDS once
+// ([level][pixel][vector]), the column pass stores straight to memory.  The LDS traffic is 6 accesses per pixel and
+// vector instead of 30.
+// Walks a line of MAXD elements once and hands emit(level, x, value) the window maxes in the order they complete, so that
+// only a few values per level are live at a time.
+template <int MAXD, typename V8, typename MAX, typename EMIT>
+__device__ __forceinline__ void window_maxes(const V8 (&a)[MAXD], V8 neg, int levels, MAX mx, EMIT emit) {
+    V8 m5[MAXD + 4], m9[MAXD + 2];
+    auto e = [&](int i) { return i >= 2 && i < MAXD + 2 ? a[i - 2] : neg; };  // e(i + 2) = element i (-inf outside the line)
+#pragma unroll
+    for (int j = 0; j < MAXD + 4; ++j) {
+        // elements j - 2 .. j + 2 = e(j) .. e(j + 4)
+        m5[j] = mx(mx(mx(e(j), e(j + 1)), mx(e(j + 2), e(j + 3))), e(j + 4));
+        if (j < MAXD) emit(0, j, m5[j]);
+        if (levels > 1 && j >= 2) {
+            const int x9 = j - 2;
+            m9[x9] = mx(m5[x9 < 2 ? 0 : x9 - 2], m5[j]);
+            if (x9 < MAXD) emit(1, x9, m9[x9]);
+            if (levels > 2 && x9 >= 2) {
+                const int x13 = x9 - 2;
+                emit(2, x13, mx(m9[x13 < 2 ? 0 : x13 - 2], m9[x9]));
+            }
+        }
+    }
+}
+
+// max of eight 16-bit values; fp16 through v_pk_max_f16 (the compiler's fmax re-rounds both operands first)
+__device__ __forceinline__ f16x8 pool_max8(f16x8 p, f16x8 q) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 a = __builtin_bit_cast(u32x4, p), b = __builtin_bit_cast(u32x4, q);
+    const u32x4 r = {pk_max2(a[0], b[0]), pk_max2(a[1], b[1]), pk_max2(a[2], b[2]), pk_max2(a[3], b[3])};
+    return __builtin_bit_cast(f16x8, r);
+}
+__device__ __forceinline__ bf16x8 pool_max8(bf16x8 p, bf16x8 q) { return Elem<bf16>::max8(p, q); }
+
+// Threads [0, 128) take the rows (all levels: each level's row maxes come from the one before); then threads
+// [128 l, 128 l + 128) take the columns of level l.
+template <int VG, int MAXD, typename ET>
+__global__ __launch_bounds__(384) void maxpool_cascade_reg_kernel(const f16* __restrict__ x, int x_ld, f16* __restrict__ y, int y_ld, int y_step,
+                                                                 int levels, int H, int W, int CG) {
+    static_assert(VG * MAXD <= 128, "a line per thread, 128 threads per level");
+    typedef typename Elem<ET>::v8 V8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    V8* planes = reinterpret_cast<V8*>(smem_raw);  // [level][H][W][VG]
+    const int b = blockIdx.x / CG, c0 = (blockIdx.x - b * CG) * VG * 8;
+    const long long pbase = (long long)b * H * W;
+    const int grp = threadIdx.x >> 7, t = threadIdx.x & 127, line = t / VG, v = t - line * VG;
+    V8 neg;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) neg[e] = (ET)(-__builtin_inff());
+    auto mx = [](V8 p, V8 q) { return pool_max8(p, q); };
+    V8 a[MAXD];
+    if (grp == 0 && line < H) {  // along row `line`
+#pragma unroll
+        for (int i = 0; i < MAXD; ++i) a[i] = i < W ? *reinterpret_cast<const V8*>(x + (pbase + line * W + i) * x_ld + c0 + v * 8) : neg;
+        window_maxes<MAXD>(a, neg, levels, mx, [&](int l, int i, V8 m) {
+            if (i < W) planes[((l * H + line) * W + i) * VG + v] = m;
+        });
+    }
+    __syncthreads();
+    if (grp < levels && line < W) {  // along column `line` of level grp
+        const int l = grp;
+#pragma unroll
+        for (int i = 0; i < MAXD; ++i) a[i] = i < H ? planes[((l * H + i) * W + line) * VG + v] : neg;
+        window_maxes<MAXD>(a, neg, l + 1, mx, [&](int ll, int i, V8 m) {
+            if (ll == l && i < H) *reinterpret_cast<V8*>(y + (pbase + i * W + line) * y_ld + (long long)l * y_step + c0 + v * 8) = m;
+        });
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void copy_channels_kernel(const f16* __restrict__ x, int x_ld, f16* __restrict__ y, int y_ld,
                                                                  long long pixels, int C8) {
     const long long total = pixels * C8;
@@ -221,6 +294,20 @@ __global__ __launch_bounds__(kThreads) void copy_channels_kernel(const f16* __re
         const long long p = i / C8;
         *reinterpret_cast<f16x8*>(y + p * y_ld + c8 * 8) = *reinterpret_cast<const f16x8*>(x + p * x_ld + c8 * 8);
     }
+}
+
+template <int VG, typename ET>
+int launch_pool_reg(const f16* xp, int x_ld, f16* yp, int y_ld, int y_step, int levels, int batch, int h, int w, int c, hipStream_t s) {
+    const size_t lds = (size_t)levels * h * w * VG * 16;
+    static std::atomic<unsigned long long> attr_set{0};
+    const unsigned long long bit = 1ull << y5_current_device();
+    if (!(attr_set.load() & bit)) {
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxpool_cascade_reg_kernel<VG, 20, ET>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 20 * 20 * VG * 16));
+        attr_set.fetch_or(bit);
+    }
+    hipLaunchKernelGGL((maxpool_cascade_reg_kernel<VG, 20, ET>), dim3((unsigned)(batch * (c / (8 * VG)))), dim3(384), lds, s, xp, x_ld, yp, y_ld, y_step, levels, h, w, c / (8 * VG));
+    Y5_LAUNCH_CHECK("maxpool_cascade_reg_kernel");
+    return Y5_OK;
 }
 
 }  // namespace
@@ -309,6 +396,8 @@ int y5_launch_maxpool_cascade(const void* x, int x_ld, void* y, int y_ld, int y_
     Y5_REQUIRE(y5_aligned16(x) && y5_aligned16(y), "maxpool_cascade: pointers must be 16-byte aligned");
     const f16* xp = static_cast<const f16*>(x);
     f16* yp = static_cast<f16*>(y);
+    if (k == 5 && levels <= 3 && h <= 20 && w <= 20 && c % 32 == 0)  // SPP on the coarsest level of an image of up to 640 x 640
+        return bf ? launch_pool_reg<4, bf16>(xp, x_ld, yp, y_ld, y_step, levels, batch, h, w, c, s) : launch_pool_reg<4, f16>(xp, x_ld, yp, y_ld, y_step, levels, batch, h, w, c, s);
     const size_t sep = (size_t)3 * h * w * 16;  // separable kernel: three planes per vector
     if (c % 16 == 0 && 2 * sep <= 64 * 1024) {
         if (bf)
