@@ -560,6 +560,53 @@ def test_conv_chain_equals_two_convolutions(dev, shape):
         assert taken >= 4
 
 
+@pytest.mark.parametrize('shape', [(3, 256, 256, 128, 128, 21, 23), (32, 256, 256, 128, 128, 40, 40), (2, 256, 256, 128, 128, 17, 9),
+                                   (2, 128, 128, 64, 64, 33, 31), (8, 128, 128, 64, 64, 80, 80), (1, 128, 128, 64, 64, 1, 5)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+@pytest.mark.parametrize('mode', ['csp', 'bias'])
+def test_persistent_1x1_chain_on_leading_channels(dev, shape, mode):
+    """The persistent 1x1 kernel with a second 1x1 convolution of the LEADING channels of its result (BottleneckCSP's
+    cv1 | cv2 followed by the first Bottleneck's cv1, models/common.py:59-60) against the same two convolutions as
+    separate y5_conv_f16 calls; pixel counts that are not whole tiles, fewer and more tiles than workgroups."""
+    lib = _lib.lib()
+    B, Ci, Cm, Cs, Co, H, W = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    st = _lib.current_stream()
+    x = torch.randn(B, H, W, Ci, generator=g).half().to(dev)
+    w1 = (torch.randn(Cm, Ci, 1, 1, generator=g) / Ci ** 0.5).half().to(dev)
+    w2 = (torch.randn(Co, Cs, 1, 1, generator=g) / Cs ** 0.5).half().to(dev)
+    b1, b2 = torch.randn(Cm, generator=g).to(dev), torch.randn(Co, generator=g).to(dev)
+    sc1, sh1 = (torch.rand(Cm, generator=g) + 0.5).to(dev), torch.randn(Cm, generator=g).to(dev)
+    if mode == 'csp':  # what the engine records: bias + scale + shift on the merged cv1 | cv2, a folded bias on m[0].cv1
+        d1, y1, k1 = _desc(dev, x, w1, bias=b1, scale=sc1, shift=sh1, slope=0.1)
+    else:
+        d1, y1, k1 = _desc(dev, x, w1, bias=b1, slope=0.1)
+    _lib.check(lib.y5_conv_f16(C.byref(d1), st))
+    d2, y2, k2 = _desc(dev, y1[..., :Cs], w2, bias=b2, slope=0.1) if mode == 'csp' else _desc(dev, y1[..., :Cs], w2, scale=sc1[:Co], shift=sh1[:Co])
+    d2.x_ld = Cm
+    _lib.check(lib.y5_conv_f16(C.byref(d2), st))
+    torch.cuda.synchronize()
+    y1_ref, y2_ref = y1.clone(), y2.clone()
+    v = lib.y5_conv_chain_num_variants() - 1
+    for variant in (v, 0) if Cs < Cm else (v,):
+        for keep_first in (1, 0):
+            y1.fill_(float('nan'))
+            y2.fill_(float('nan'))
+            d1.y = y1.data_ptr() if keep_first else None
+            _lib.check(lib.y5_conv_chain_f16(C.byref(d1), C.byref(d2), keep_first, variant, st))
+            torch.cuda.synchronize()
+            if keep_first:
+                close(y1.permute(0, 3, 1, 2), y1_ref.permute(0, 3, 1, 2))
+                assert float((y1 == y1_ref).float().mean()) > 0.99
+            else:
+                assert bool(torch.isnan(y1).all()), 'the intermediate tensor must not be written'
+            assert not bool(torch.isnan(y2).any())
+            close(y2.permute(0, 3, 1, 2), y2_ref.permute(0, 3, 1, 2), rel=4e-3)
+    if Cs < Cm:  # the other kernels of the family read all of the first result
+        d1.y = y1.data_ptr()
+        assert lib.y5_conv_chain_f16(C.byref(d1), C.byref(d2), 1, 1, st) == _lib.EINVAL
+
+
 @pytest.mark.parametrize('shape', [(2, 64, 96, 32), (3, 41, 74, 16), (1, 130, 66, 56), (2, 8, 200, 13)], ids=lambda s: 'x'.join(map(str, s)))
 def test_stem_conv_from_the_nchw_image(dev, shape):
     """y5_stem_conv_f16 / _u8 (first-layer 3x3 conv straight from the NCHW image) against torch's fp32 convolution with

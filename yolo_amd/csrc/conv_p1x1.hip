@@ -50,8 +50,11 @@ __global__ __launch_bounds__(NTH) void conv_p1x1_kernel(const P1Args a) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int t = threadIdx.x, lane = t & 63, lr = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    // The workgroup's share: an equal, contiguous run of PIXELS (these layers are bound by memory: equal bytes per CU), walked
+    // in tiles of TP pixels from its first pixel; the run's last tile may be partial.
     const int nwg = gridDim.x, g = xcd_remap(blockIdx.x, nwg);
-    const int first = (int)((long long)g * a.ntiles / nwg), last = (int)((long long)(g + 1) * a.ntiles / nwg);
+    const int run0 = (int)((long long)g * a.npix / nwg), run1 = (int)((long long)(g + 1) * a.npix / nwg);
+    const int first = 0, last = (run1 - run0 + Cfg::TP - 1) / Cfg::TP;
 
     float* prm = reinterpret_cast<float*>(smem + Cfg::PRM0);
     for (int i = t; i < Cfg::CO; i += NTH) {
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(NTH) void conv_p1x1_kernel(const P1Args a) {
         rel[j] = px * (a.x_ld * 2) + ((sp ^ (px & 15)) << 4);
     }
     auto issue = [&](int tile, int buf) {
-        const int pix0 = tile * Cfg::TP, left = a.npix - pix0;
+        const int pix0 = run0 + tile * Cfg::TP, left = run1 - pix0;
         const int base = pix0 * (a.x_ld * 2);
 #pragma unroll
         for (int j = 0; j < MYP; ++j)
@@ -126,17 +129,200 @@ __global__ __launch_bounds__(NTH) void conv_p1x1_kernel(const P1Args a) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MYP) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int pix0 = tile * Cfg::TP;
+        const int pix0 = run0 + tile * Cfg::TP;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int pix = pix0 + (pg * NT + nt) * 32 + lr;
-            if (pix < a.npix) {
+            if (pix < run1) {
                 f16* yp = a.y + (size_t)pix * a.y_ld + mt * 32 + 16 * lh;
                 *reinterpret_cast<f16x8*>(yp) = lo[nt];
                 *reinterpret_cast<f16x8*>(yp + 8) = hi[nt];
             }
         }
         buf = buf == NBUF - 1 ? 0 : buf + 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same kernel with a SECOND 1x1 convolution on the finished tile (BottleneckCSP's cv1 | cv2 followed by the first
+// Bottleneck's cv1, which reads the cv1 half): the first result's leading
+// 16 KS2 channels go from the registers into an LDS tile ([pixel][channel], slots swizzled like the input tiles), the
+// eight waves regroup as (32 NCW2 output channels) x (32-pixel groups) and multiply that tile with the second layer's
+// weights, which also stay in registers.  The first result is stored only if something else reads it (a.y != nullptr).
+// Both stages apply bias, scale + shift and LeakyReLU from LDS-staged parameters (absent ones are 0 / 1 / 0, which
+// leaves the roundings of the one-layer kernels unchanged).
+struct P1ChainArgs {
+    P1Args f;
+    const f16* w2;
+    const float *bias2, *scale2, *shift2;
+    f16* y2;
+    int w2_ld, y2_ld;
+    float slope2;
+};
+
+template <int KS, int NCW, int KS2, int NCW2>
+struct P1ChainCfg {
+    static constexpr int CI = 16 * KS, CO = 32 * NCW, PXW = NWC / NCW;
+    static constexpr int CI2 = 16 * KS2, CO2 = 32 * NCW2, PXW2 = NWC / NCW2;
+    static_assert(CI2 <= CO && CI2 % 32 == 0, "the second layer reads leading whole channel blocks of the first result");
+    static constexpr int TP = 32 * PXW2, NT = TP / (32 * PXW);  // one 32-pixel group per wave in the second stage
+    static_assert(NT >= 1 && NT * 32 * PXW == TP, "the first stage covers the tile with whole pixel groups");
+    static constexpr int SLOTS = 2 * KS, XROW = SLOTS * 16;
+    static_assert(SLOTS >= 16 && (SLOTS & (SLOTS - 1)) == 0, "the swizzle needs rows of 16 slots or more");
+    static constexpr int X_BYTES = TP * XROW, PIECES = X_BYTES / 1024, MYP = PIECES / NWC;
+    static_assert(MYP * NWC * 1024 == X_BYTES, "every wave copies the same number of whole pieces");
+    static constexpr int TROW = CI2 * 2, T_BYTES = TP * TROW;  // the first result's tile (two of them); 128-byte rows swizzle by pixel pairs
+    static constexpr int T0 = NBUF * X_BYTES, PRM0 = T0 + 2 * T_BYTES, SMEM = PRM0 + 3 * (CO + CO2) * 4;
+    static_assert(SMEM <= 160 * 1024, "fits the CU's LDS");
+    __device__ static __forceinline__ int tswz(int px) { return TROW >= 256 ? (px & 15) : ((px >> 1) & 7); }
+};
+
+template <int KS, int NCW, int KS2, int NCW2>
+__global__ __launch_bounds__(NTH) void conv_p1x1_chain_kernel(const P1ChainArgs c) {
+    typedef P1ChainCfg<KS, NCW, KS2, NCW2> Cfg;
+    constexpr int MYP = Cfg::MYP, NT = Cfg::NT;
+    const P1Args& a = c.f;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int t = threadIdx.x, lane = t & 63, lr = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int nwg = gridDim.x, g = xcd_remap(blockIdx.x, nwg);  // equal runs of pixels, as in conv_p1x1_kernel
+    const int run0 = (int)((long long)g * a.npix / nwg), run1 = (int)((long long)(g + 1) * a.npix / nwg);
+    const int first = 0, last = (run1 - run0 + Cfg::TP - 1) / Cfg::TP;
+
+    float* prm = reinterpret_cast<float*>(smem + Cfg::PRM0);
+    float* prm2 = prm + 3 * Cfg::CO;
+    for (int i = t; i < Cfg::CO; i += NTH) {
+        prm[i] = a.bias ? a.bias[i] : 0.f;
+        prm[Cfg::CO + i] = a.scale ? a.scale[i] : 1.f;
+        prm[2 * Cfg::CO + i] = a.scale ? a.shift[i] : 0.f;
+    }
+    for (int i = t; i < Cfg::CO2; i += NTH) {
+        prm2[i] = c.bias2 ? c.bias2[i] : 0.f;
+        prm2[Cfg::CO2 + i] = c.scale2 ? c.scale2[i] : 1.f;
+        prm2[2 * Cfg::CO2 + i] = c.scale2 ? c.shift2[i] : 0.f;
+    }
+
+    const int mt = wave % NCW, pg = wave / NCW;      // first stage: output channels [32 mt, +32), pixels [32 NT pg, +32 NT)
+    const int mt2 = wave % NCW2, pg2 = wave / NCW2;  // second stage: output channels [32 mt2, +32), pixels [32 pg2, +32)
+    f16x8 wf[KS], wg[KS2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) wf[ks] = *reinterpret_cast<const f16x8*>(a.w + (size_t)(mt * 32 + perm_row(lr)) * a.w_ld + ks * 16 + lh * 8);
+#pragma unroll
+    for (int ks = 0; ks < KS2; ++ks) wg[ks] = *reinterpret_cast<const f16x8*>(c.w2 + (size_t)(mt2 * 32 + perm_row(lr)) * c.w2_ld + ks * 16 + lh * 8);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // from here on the only loads in flight are the copies counted below
+
+    const i32x4 xr = make_buf(a.x, a.x_bytes);
+    int rel[MYP], cpx[MYP];
+#pragma unroll
+    for (int j = 0; j < MYP; ++j) {
+        const int slot = (wave + NWC * j) * 64 + lane, px = slot / Cfg::SLOTS, sp = slot % Cfg::SLOTS;
+        cpx[j] = px;
+        rel[j] = px * (a.x_ld * 2) + ((sp ^ (px & 15)) << 4);
+    }
+    auto issue = [&](int tile, int buf) {
+        const int pix0 = run0 + tile * Cfg::TP, left = run1 - pix0;
+        const int base = pix0 * (a.x_ld * 2);
+#pragma unroll
+        for (int j = 0; j < MYP; ++j)
+            dma16_buf(xr, cpx[j] < left ? (unsigned)(base + rel[j]) : Y5_BUF_OOB, (unsigned)(buf * Cfg::X_BYTES + (wave + NWC * j) * 1024));
+    };
+
+    int uoff[NT], toff[NT];  // first stage: fragment offset in the input tile, and where the lane's 16 result channels go in T
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int px = (pg * NT + nt) * 32 + lr;
+        uoff[nt] = px * Cfg::XROW + ((lh ^ (px & 15)) << 4);
+        toff[nt] = Cfg::T0 + px * Cfg::TROW;
+    }
+    const int px2 = pg2 * 32 + lr;
+    const int voff = Cfg::T0 + px2 * Cfg::TROW + ((lh ^ Cfg::tswz(px2)) << 4);  // second stage: K-step ks at voff ^ (ks << 5)
+    float negzero;
+    asm volatile("v_mov_b32 %0, 0x80000000" : "=v"(negzero));
+
+    if (first < last) issue(first, 0);
+    if (first + 1 < last) {
+        issue(first + 1, 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MYP) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // The second stage runs one tile behind the first (two T buffers): one barrier per tile orders both, and the waves have
+    // the second stage's products of tile i - 1 to issue beside the first stage's of tile i.
+    auto second = [&](int tile) {
+        f32x16 acc = zero16();
+        const unsigned char* T = smem + ((tile & 1) ? Cfg::T_BYTES : 0);
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wg[ks], *reinterpret_cast<const f16x8*>(T + (voff ^ (ks << 5))), acc, 0, 0, 0);
+        f16x8 l2, h2;
+        finish<3>(acc, prm2, Cfg::CO2, mt2 * 32 + 16 * lh, c.slope2, negzero, l2, h2);
+        const int pix = run0 + tile * Cfg::TP + px2;
+        if (pix < run1) {
+            f16* yp = c.y2 + (size_t)pix * c.y2_ld + mt2 * 32 + 16 * lh;
+            *reinterpret_cast<f16x8*>(yp) = l2;
+            *reinterpret_cast<f16x8*>(yp + 8) = h2;
+        }
+    };
+    // The waves never wait for their own stores: the one vmcnt wait per tile sits right before the NEXT tile's barrier and
+    // only asks for that tile's pieces (issued a whole iteration earlier) - everything issued after them may stay in flight:
+    // the previous iteration's stores, the pieces issued at the top of this one, this iteration's stores.  (Only the last
+    // tile of a run can be ragged and skip store instructions; no wait follows it.)
+    const int su = a.y ? 2 * NT : 0;  // store instructions of a full tile's first result
+    int buf = 0, after = 0;           // vector-memory instructions issued since the next tile's pieces
+    for (int tile = first; tile < last; ++tile) {
+        // this tile's pieces have landed and tile - 1's T is complete; tile - 1's input and tile - 2's T are read
+        if (tile == first) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else {
+            switch (after) {
+#define Y5_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+                Y5_W(2) Y5_W(4) Y5_W(6) Y5_W(8) Y5_W(10) Y5_W(12) Y5_W(14) Y5_W(16)
+#undef Y5_W
+                default: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+            }
+        }
+        // instructions issued after the pieces of tile + 1 (which went out at the top of the previous iteration, or before the
+        // loop for the second tile): the previous iteration's stores, then this iteration's pieces and stores
+        after = tile == first ? 0 : su + (tile - 1 > first ? 2 : 0);
+        if (tile + 2 < last) {
+            issue(tile + 2, buf == 0 ? NBUF - 1 : buf - 1);
+            after += MYP;
+        }
+        after += su + (tile > first ? 2 : 0);
+        const unsigned char* X = smem + buf * Cfg::X_BYTES;
+        unsigned char* T = smem + ((tile & 1) ? Cfg::T_BYTES : 0);
+        f16x8 lo[NT], hi[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x16 acc = zero16();
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], *reinterpret_cast<const f16x8*>(X + (uoff[nt] ^ (ks << 5))), acc, 0, 0, 0);
+            finish<3>(acc, prm, Cfg::CO, mt * 32 + 16 * lh, a.slope, negzero, lo[nt], hi[nt]);  // parameters from LDS: the registers hold weights
+            if (mt * 32 < Cfg::CI2) {  // wave-uniform: this channel block feeds the second layer
+                const int px = (pg * NT + nt) * 32 + lr, s0 = 4 * mt + 2 * lh, f = Cfg::tswz(px);
+                *reinterpret_cast<f16x8*>(T + toff[nt] + ((s0 ^ f) << 4)) = lo[nt];
+                *reinterpret_cast<f16x8*>(T + toff[nt] + (((s0 + 1) ^ f) << 4)) = hi[nt];
+            }
+        }
+        if (a.y) {
+            const int pix0 = run0 + tile * Cfg::TP;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int pix = pix0 + (pg * NT + nt) * 32 + lr;
+                if (pix < run1) {
+                    f16* yp = a.y + (size_t)pix * a.y_ld + mt * 32 + 16 * lh;
+                    *reinterpret_cast<f16x8*>(yp) = lo[nt];
+                    *reinterpret_cast<f16x8*>(yp + 8) = hi[nt];
+                }
+            }
+        }
+        if (tile > first) second(tile - 1);
+        buf = buf == NBUF - 1 ? 0 : buf + 1;
+    }
+    if (first < last) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the last tile's T is complete
+        second(last - 1);
     }
 }
 
@@ -173,6 +359,22 @@ int launch(P1Args& a, int f, hipStream_t s) {
     return f == 0 ? launch_f<KS, NCW, NT, 0>(a, s) : f == 1 ? launch_f<KS, NCW, NT, 1>(a, s) : f == 2 ? launch_f<KS, NCW, NT, 2>(a, s) : launch_f<KS, NCW, NT, 3>(a, s);
 }
 
+template <int KS, int NCW, int KS2, int NCW2>
+int launch_chain(P1ChainArgs& c, hipStream_t s) {
+    typedef P1ChainCfg<KS, NCW, KS2, NCW2> Cfg;
+    static std::atomic<unsigned long long> attr_set{0};
+    const unsigned long long bit = 1ull << y5_current_device();
+    if (!(attr_set.load() & bit)) {
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p1x1_chain_kernel<KS, NCW, KS2, NCW2>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+        attr_set.fetch_or(bit);
+    }
+    c.f.ntiles = (c.f.npix + Cfg::TP - 1) / Cfg::TP;
+    const int cus = cu_count();
+    hipLaunchKernelGGL((conv_p1x1_chain_kernel<KS, NCW, KS2, NCW2>), dim3((unsigned)(c.f.ntiles < cus ? c.f.ntiles : cus)), dim3(NTH), (size_t)Cfg::SMEM, s, c);
+    Y5_LAUNCH_CHECK("conv_p1x1_chain_kernel");
+    return Y5_OK;
+}
+
 }  // namespace
 
 int y5_conv_p1x1_count() { return 2; }
@@ -204,5 +406,35 @@ int y5_try_conv_p1x1(const y5_conv_desc& d, hipStream_t s, int which, int* rc) {
     } else {
         *rc = which == 1 ? launch<8, 8, 2>(a, f, s) : launch<8, 8, 1>(a, f, s);
     }
+    return 1;
+}
+
+// f followed by g, a 1x1 stride-1 convolution of the first g.cin channels of f's result (f's result is stored only if
+// keep_first).  Compiled for f: 256 -> 256 with g: 128 -> 128, and f: 128 -> 128 with g: 64 -> 64.  Returns 0
+// when the pair is outside that (then *rc is untouched), 1 after a launch attempt with its status in *rc.  Both
+// descriptors were validated by y5_launch_conv_chain.
+int y5_try_conv_p1x1_chain(const y5_conv_desc& f, const y5_conv_desc& g, int keep_first, hipStream_t s, int* rc) {
+    if (f.ksize != 1 || f.stride != 1 || f.pad != 0 || f.res || g.res) return 0;
+    const int shape = f.cin == 256 && f.cout == 256 && g.cin == 128 && g.cout == 128 ? 1 : f.cin == 128 && f.cout == 128 && g.cin == 64 && g.cout == 64 ? 3 : 0;
+    if (!shape) return 0;
+    if (f.w_rows < f.cout || f.kpad < f.cin || g.w_rows < g.cout || g.kpad < g.cin) return 0;
+    const long long npix = (long long)f.batch * f.h * f.w_in;
+    const long long xb = ((npix - 1) * f.x_ld + f.cin) * 2;
+    if (npix <= 0 || npix >= 0x7fffffffLL || xb >= 0x7fffffffLL) return 0;
+    P1ChainArgs c{};
+    P1Args& a = c.f;
+    a.x = static_cast<const f16*>(f.x);
+    a.y = keep_first ? static_cast<f16*>(f.y) : nullptr;
+    a.w = static_cast<const f16*>(f.w);
+    a.bias = f.bias; a.scale = f.scale; a.shift = f.shift;
+    a.w_ld = f.kpad; a.x_ld = f.x_ld; a.y_ld = f.y_ld; a.x_bytes = (int)xb;
+    a.npix = (int)npix;
+    a.slope = f.act == Y5_ACT_LEAKY ? f.slope : 1.f;
+    c.w2 = static_cast<const f16*>(g.w);
+    c.bias2 = g.bias; c.scale2 = g.scale; c.shift2 = g.shift;
+    c.y2 = static_cast<f16*>(g.y);
+    c.w2_ld = g.kpad; c.y2_ld = g.y_ld;
+    c.slope2 = g.act == Y5_ACT_LEAKY ? g.slope : 1.f;
+    *rc = shape == 1 ? launch_chain<16, 8, 8, 4>(c, s) : launch_chain<8, 4, 4, 2>(c, s);
     return 1;
 }

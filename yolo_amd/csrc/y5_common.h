@@ -129,6 +129,7 @@ int y5_conv_s2c64_count();
 // 1x1 persistent kernel for 128 / 256 channels (conv_p1x1.hip): two variants, numbered before the stride-2 ones
 int y5_try_conv_p1x1(const y5_conv_desc& d, hipStream_t s, int which, int* rc);
 int y5_conv_p1x1_count();
+int y5_try_conv_p1x1_chain(const y5_conv_desc& f, const y5_conv_desc& g, int keep_first, hipStream_t s, int* rc);
 int y5_launch_detect(const y5_conv_desc& c, const y5_decode_desc& d, int variant, hipStream_t s);
 int y5_detect_variant_count();
 int y5_try_detect_persistent(const y5_conv_desc& c, const y5_decode_desc& d, hipStream_t s, int* rc);

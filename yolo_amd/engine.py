@@ -418,7 +418,7 @@ class Plan:
         tune = os.environ.get('Y5_AUTOTUNE', '1') != '0'
         best, best_ms = 0, float('inf')
         if self.lib.y5_conv_chain_f16(C.byref(d1), C.byref(d2), keep_first, 0, stream) == 0:
-            key = ('chain', keep_first, d1.batch, d1.h, d1.w_in, d1.cin, d1.x_ld, d1.cout, d1.ksize, d1.stride, bool(d1.res), d2.cout, d2.y_ld)
+            key = ('chain', keep_first, d1.batch, d1.h, d1.w_in, d1.cin, d1.x_ld, d1.cout, d1.ksize, d1.stride, bool(d1.res), d2.cin, d2.cout, d2.y_ld)
             if key not in _TUNED and tune:
                 x1.buf.uniform_(-1.0, 1.0)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -449,6 +449,13 @@ class Plan:
         self.labels.append('%s v%d' % (t1, d1.variant))
         _lib.check(self.lib.y5_plan_add_conv(self.handle, C.byref(d2)))
         self.labels.append('%s v%d' % (t2, d2.variant))
+
+    def _emit_deferred(self, deferred):
+        """Record a convolution that _emit_conv handed back (self._defer) as a kernel of its own."""
+        text, d, x = deferred
+        d.variant = self._tune(d, x)
+        _lib.check(self.lib.y5_plan_add_conv(self.handle, C.byref(d)))
+        self.labels.append('%s v%d' % (text, d.variant))
 
     def _tune(self, d, x):
         """Pick the fastest compiled tile configuration for this convolution by timing every applicable one on
@@ -973,6 +980,7 @@ class Plan:
 
     def _csp_layers(self, name, m, x, out):
         """BottleneckCSP layer by layer (see _csp)."""
+        head = None
         c1, c2, c3 = m.cv1.conv.out_channels, m.cv2.out_channels, m.cv3.out_channels
         scale, shift = bn_affine(m.bn)
         slope = self._slope(m.act)
@@ -996,9 +1004,14 @@ class Plan:
                 sc1[:c1], sh1[:c1] = s1, h1
             sc2, sh2 = torch.zeros(p2, device=dev), torch.zeros(p2, device=dev)
             sc2[:c2], sh2[:c2] = scale[c3:], shift[c3:]
-            self._emit_conv(name + '.cv1+cv2', x, [(m.cv1.conv.weight, p1), (m.cv2.weight, p2)], 1, 1, U,
-                            bias=torch.cat((b1, torch.zeros(p2, device=dev))), scale=torch.cat((sc1, sc2)),
-                            shift=torch.cat((sh1, sh2)), slope=slope)
+            if not isinstance(x, Cat2):
+                self._defer = []  # recorded below, alone or chained with the first Bottleneck's cv1
+            try:
+                self._emit_conv(name + '.cv1+cv2', x, [(m.cv1.conv.weight, p1), (m.cv2.weight, p2)], 1, 1, U,
+                                bias=torch.cat((b1, torch.zeros(p2, device=dev))), scale=torch.cat((sc1, sc2)),
+                                shift=torch.cat((sh1, sh2)), slope=slope)
+            finally:
+                head, self._defer = self._defer, None
             t = U.slice(0, [(c1, p1)])
             cat = Act(U.buf, U.off, U.ld, U.batch, U.h, U.w, [(c3, pad8(c3)), (c2, p2)])
         else:
@@ -1015,6 +1028,19 @@ class Plan:
         # next shortcut needs it): the 1x1 then reads its input from LDS instead of HBM.  Measured per shape like the rest.
         link = chain and os.environ.get('Y5_CHAIN_LINK', '1') != '0'
         hidden = None
+        if head:
+            # cv1 | cv2 and the first Bottleneck's cv1 (a 1x1 of the cv1 half) as one kernel where that measures faster:
+            # the half is multiplied again while its tile is still on the CU
+            if chain and os.environ.get('Y5_CHAIN_HEAD', '1') != '0' and _conv_geometry(bots[0].cv1.conv) == (1, 1):
+                hidden = self._new_act(x.batch, x.h, x.w, [(bots[0].cv1.conv.out_channels, pad8(bots[0].cv1.conv.out_channels))])
+                self._defer = []
+                try:
+                    self._conv_block('%s.m0.cv1' % name, bots[0].cv1, t, hidden)
+                finally:
+                    defs, self._defer = self._defer, None
+                self._emit_chain(head + defs, keep_first=1)
+            else:
+                self._emit_deferred(head[0])
         for bi, b in enumerate(bots[:-1] if chain else bots):
             nxt = self._new_act(x.batch, x.h, x.w, [(b.cv2.conv.out_channels, pad8(b.cv2.conv.out_channels))])
             if not link:
