@@ -104,7 +104,11 @@ int y5_conv_num_variants_bf16(void);
  * intermediate tensor: first.y is written only if keep_first != 0 (it may be NULL otherwise); second.x is ignored.
  * Both channel counts must fit one tile of the chosen variant (at most 256; Y5_EINVAL otherwise) and both weight
  * tensors must be packed to that many rows.  variant: 0 or 1..y5_conv_chain_num_variants().  Same values as the two
- * separate calls up to the fp32 summation order. */
+ * separate calls up to the fp32 summation order.
+ * second.cin may be smaller than first.cout: second then reads the LEADING second.cin channels of first's result
+ * (BottleneckCSP.cv1 and cv2 recorded as one convolution, followed by the first Bottleneck's cv1, which reads the cv1
+ * half: models/common.py:59-60, :41).  Only the last variant but one, a persistent 1x1 kernel compiled for
+ * 256 -> 256 with 128 -> 128 and 128 -> 128 with 64 -> 64 channels, takes such a pair (variant 0 selects it). */
 int y5_conv_chain_f16(const y5_conv_desc* first, const y5_conv_desc* second, int keep_first, int variant, y5_stream_t stream);
 int y5_conv_chain_num_variants(void);
 
