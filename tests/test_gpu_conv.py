@@ -506,7 +506,10 @@ def _desc(dev, x_nhwc, w, bias=None, scale=None, shift=None, slope=None, res=Non
 
 @pytest.mark.parametrize('shape', [(2, 32, 32, 32, 40, 24, 3, 1), (3, 64, 64, 64, 20, 20, 3, 1), (1, 128, 128, 128, 20, 12, 3, 1),
                                    (2, 24, 40, 56, 17, 9, 3, 1), (2, 64, 64, 32, 24, 24, 1, 1), (1, 64, 128, 64, 16, 16, 3, 2),
-                                   (1, 64, 64, 64, 8, 16, 3, 1), (2, 64, 64, 64, 16, 48, 3, 1), (5, 64, 64, 64, 80, 80, 3, 1)],
+                                   (1, 64, 64, 64, 8, 16, 3, 1), (2, 64, 64, 64, 16, 48, 3, 1), (5, 64, 64, 64, 80, 80, 3, 1),
+                                   # the weights-in-registers 128-channel kernel: whole and ragged strips, narrow and full-width rows
+                                   (32, 128, 128, 128, 40, 40, 3, 1), (2, 128, 128, 128, 33, 40, 3, 1), (3, 128, 128, 128, 7, 5, 3, 1),
+                                   (2, 128, 128, 128, 4, 37, 3, 1)],
                          ids=lambda s: 'x'.join(map(str, s)))
 def test_conv_chain_equals_two_convolutions(dev, shape):
     """y5_conv_chain_f16 (conv + residual, then a 1x1 conv of the result, one kernel) against the same two convolutions
@@ -546,6 +549,8 @@ def test_conv_chain_equals_two_convolutions(dev, shape):
                 rc = lib.y5_conv_chain_f16(C.byref(d1), C.byref(d2), keep_first, v, st)
                 if v == lib.y5_conv_chain_num_variants() and (Ci, Cm, Co, k, s) == (64, 64, 64, 3, 1) and H % 8 == 0 and W % 16 == 0:
                     assert rc == 0, 'the persistent 64-channel kernel takes this shape'
+                if v == lib.y5_conv_chain_num_variants() - 2 and (Ci, Cm, Co, k, s) == (128, 128, 128, 3, 1) and W <= 40:
+                    assert rc == 0, 'the 128-channel weights-in-registers kernel takes this shape'
                 if v and rc == _lib.EINVAL:
                     continue
                 _lib.check(rc)

@@ -154,7 +154,7 @@ extern "C" int y5_conv_chain_f16(const y5_conv_desc* first, const y5_conv_desc* 
     return y5_launch_conv_chain(*first, *second, keep_first, variant, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int y5_conv_chain_num_variants(void) { return y5_conv_lw_count() + 2; }
+extern "C" int y5_conv_chain_num_variants(void) { return y5_conv_lw_count() + 3; }
 
 extern "C" int y5_conv_cat2_f16(const y5_conv_desc* d, const void* x2, int x2_ld, int cin2, y5_stream_t stream) {
     Y5_REQUIRE(d, "conv_cat2: null descriptor");

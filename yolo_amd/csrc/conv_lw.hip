@@ -774,7 +774,7 @@ int y5_try_conv_lw(const y5_conv_desc& d, hipStream_t s, int which, int* rc) {
 // variant: 0 = the first tile shape that holds both channel counts, else 1..y5_conv_lw_count().
 int y5_launch_conv_chain(const y5_conv_desc& f, const y5_conv_desc& g, int keep_first, int variant, hipStream_t s) {
     Y5_REQUIRE(f.dtype == Y5_F16 && g.dtype == Y5_F16, "conv chain: fp16 only");
-    Y5_REQUIRE(variant >= 0 && variant <= y5_conv_lw_count() + 2, "conv chain: variant %d out of range 0..%d", variant, y5_conv_lw_count() + 2);
+    Y5_REQUIRE(variant >= 0 && variant <= y5_conv_lw_count() + 3, "conv chain: variant %d out of range 0..%d", variant, y5_conv_lw_count() + 3);
     Y5_REQUIRE(f.x && f.w && g.w && g.y && (f.y || !keep_first), "conv chain: null tensor pointer");
     Y5_REQUIRE(f.ksize == 3 || (f.ksize == 1 && f.stride == 1), "conv chain: the first convolution is 3x3 or 1x1 stride 1");
     Y5_REQUIRE(f.stride == 1 || f.stride == 2, "conv chain: stride %d not in {1,2}", f.stride);
@@ -790,7 +790,7 @@ int y5_launch_conv_chain(const y5_conv_desc& f, const y5_conv_desc& g, int keep_
     const bool part = g.cin < f.cout;
     Y5_REQUIRE(g.batch == f.batch && g.h == f.ho && g.w_in == f.wo && g.ho == f.ho && g.wo == f.wo && g.cin > 0 && g.cin <= f.cout,
                "conv chain: the second convolution must take the first one's output");
-    Y5_REQUIRE(!part || variant == 0 || variant == y5_conv_lw_count() + 1, "conv chain: variant %d reads all %d channels of the first result, not %d", variant, f.cout, g.cin);
+    Y5_REQUIRE(!part || variant == 0 || variant == y5_conv_lw_count() + 2, "conv chain: variant %d reads all %d channels of the first result, not %d", variant, f.cout, g.cin);
     Y5_REQUIRE(g.cout > 0 && g.cout % 8 == 0 && g.y_ld % 8 == 0 && g.y_ld >= g.cout, "conv chain: cout %d / y_ld %d of the second convolution", g.cout, g.y_ld);
     Y5_REQUIRE(g.kpad % 8 == 0 && g.kpad >= (g.cin + 15) / 16 * 16, "conv chain: second weights need kpad >= %d", (g.cin + 15) / 16 * 16);
     Y5_REQUIRE(!g.scale || g.shift, "conv chain: scale without shift");
@@ -800,12 +800,17 @@ int y5_launch_conv_chain(const y5_conv_desc& f, const y5_conv_desc& g, int keep_
         Y5_REQUIRE(d->act == Y5_ACT_NONE || (d->act == Y5_ACT_LEAKY && d->slope > 0.f && d->slope <= 1.f), "conv chain: bad activation");
         Y5_REQUIRE(y5_aligned16(d->bias) && y5_aligned16(d->scale) && y5_aligned16(d->shift), "conv chain: per-channel vectors must be 16-byte aligned");
     }
-    if (variant == y5_conv_lw_count() + 1 || (variant == 0 && part)) {  // the persistent 1x1 kernel of conv_p1x1.hip
+    if (variant == y5_conv_lw_count() + 1) {  // the weights-in-registers 128-channel kernel of conv_c128.hip
+        int rc = Y5_OK;
+        if (y5_try_conv_c128_chain(f, g, keep_first, s, &rc)) return rc;
+        return y5_fail(Y5_EINVAL, "conv chain: the 128-channel variant takes 3x3 stride 1, 128 -> 128 -> 128 channels, width <= 40");
+    }
+    if (variant == y5_conv_lw_count() + 2 || (variant == 0 && part)) {  // the persistent 1x1 kernel of conv_p1x1.hip
         int rc = Y5_OK;
         if (y5_try_conv_p1x1_chain(f, g, keep_first, s, &rc)) return rc;
         return y5_fail(Y5_EINVAL, "conv chain: the persistent 1x1 variant takes 256 -> 256 -> (128 ->) 128 and 128 -> 128 -> (64 ->) 64 channels");
     }
-    if (variant == y5_conv_lw_count() + 2) {  // the persistent 64-channel kernel of conv_c64.hip
+    if (variant == y5_conv_lw_count() + 3) {  // the persistent 64-channel kernel of conv_c64.hip
         int rc = Y5_OK;
         if (y5_try_conv_c64_chain(f, g, keep_first, s, &rc)) return rc;
         return y5_fail(Y5_EINVAL, "conv chain: the last variant takes 3x3 stride 1, 64 -> 64 -> 64 channels, height %% 8 == 0, width %% 16 == 0");

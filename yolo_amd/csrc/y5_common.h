@@ -135,6 +135,7 @@ int y5_detect_variant_count();
 int y5_try_detect_persistent(const y5_conv_desc& c, const y5_decode_desc& d, hipStream_t s, int* rc);
 int y5_launch_conv_chain(const y5_conv_desc& f, const y5_conv_desc& g, int keep_first, int variant, hipStream_t s);
 int y5_try_conv_c64_chain(const y5_conv_desc& f, const y5_conv_desc& g, int keep_first, hipStream_t s, int* rc);
+int y5_try_conv_c128_chain(const y5_conv_desc& f, const y5_conv_desc& g, int keep_first, hipStream_t s, int* rc);
 int y5_conv_variant_count();
 // BottleneckCSP with one Bottleneck as one kernel (conv_csp.hip)
 int y5_launch_csp(const y5_csp_desc& d, hipStream_t s);
