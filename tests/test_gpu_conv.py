@@ -400,17 +400,24 @@ def test_focus_and_the_stride2_conv_in_one_kernel(dev, shape, mode):
         _lib.check(lib.y5_focus_conv_f16(C.byref(d0), st))
         _lib.check(lib.y5_conv_f16(C.byref(d1), st))
         outs[name] = y
-    y = torch.full((B, H // 4, W // 4, 64), float('nan'), dtype=torch.float16, device=dev)
-    d1.y, d1.variant, d0.y = y.data_ptr(), 0, None
-    _lib.check(lib.y5_focus_conv2_f16(C.byref(d0), C.byref(d1), st))
-    torch.cuda.synchronize()
-    assert not bool(torch.isnan(y).any())
-    if mode == 'bias':
-        assert torch.equal(y, outs['persistent'])
-    else:  # the scale + shift step is one fused multiply-add here: isolated values one fp16 step from the two-kernel path
-        close(y.permute(0, 3, 1, 2), outs['persistent'].permute(0, 3, 1, 2), rel=1e-3)
-        assert float((y == outs['persistent']).float().mean()) > 0.999
-    close(y.permute(0, 3, 1, 2), outs['rule'].permute(0, 3, 1, 2))
+    ys = []
+    for v in (0, 1):  # tile by tile / layer 1 of a tile beside layer 0 of the next: the same sums in the same order
+        y = torch.full((B, H // 4, W // 4, 64), float('nan'), dtype=torch.float16, device=dev)
+        d1.y, d1.variant, d0.y, d0.variant = y.data_ptr(), 0, None, v
+        _lib.check(lib.y5_focus_conv2_f16(C.byref(d0), C.byref(d1), st))
+        torch.cuda.synchronize()
+        assert not bool(torch.isnan(y).any())
+        if mode == 'bias':
+            assert torch.equal(y, outs['persistent'])
+        else:  # the scale + shift step is one fused multiply-add here: isolated values one fp16 step from the two-kernel path
+            close(y.permute(0, 3, 1, 2), outs['persistent'].permute(0, 3, 1, 2), rel=1e-3)
+            assert float((y == outs['persistent']).float().mean()) > 0.999
+        close(y.permute(0, 3, 1, 2), outs['rule'].permute(0, 3, 1, 2))
+        ys.append(y)
+    assert torch.equal(ys[0], ys[1])
+    d0.variant = 2
+    assert lib.y5_focus_conv2_f16(C.byref(d0), C.byref(d1), st) == _lib.EINVAL
+    d0.variant = 0
     d1.ho = d1.ho + 1
     assert lib.y5_focus_conv2_f16(C.byref(d0), C.byref(d1), st) == _lib.EINVAL
 

@@ -1,5 +1,6 @@
 """Where the one-kernel Focus + stride-2 conv spends its time, from in-kernel cycle stamps (diagnostic library built by
-`make -C yolo_amd/csrc dbg`).  usage: stamp_stem2.py [batch] [H] [W]"""
+`make -C yolo_amd/csrc dbg`).  usage: stamp_stem2.py [batch] [H] [W] [variant]
+With the production library: launch time of the chosen variant, and its output compared bit for bit with variant 0's."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,6 +12,7 @@ lib = C.CDLL(os.path.join(ROOT, 'yolo_amd', os.environ.get('Y5_DBG_LIB', 'liby5h
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 640
 W = int(sys.argv[3]) if len(sys.argv) > 3 else 640
+VARIANT = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 dev = torch.device('cuda:0')
 img = torch.rand(B, 3, H, W, device=dev).half()
 w0 = torch.zeros(128, 192, dtype=torch.float16, device=dev); w0[:32, :144] = (torch.randn(32, 144, device=dev) / 10).half()
@@ -24,6 +26,7 @@ d0.ksize, d0.stride, d0.pad, d0.kpad, d0.w_rows, d0.act, d0.slope = 3, 1, 1, 192
 d1.w, d1.y, d1.bias = w1.data_ptr(), y.data_ptr(), b1.data_ptr()
 d1.batch, d1.h, d1.w_in, d1.cin, d1.x_ld, d1.ho, d1.wo, d1.cout, d1.y_ld = B, H // 2, W // 2, 32, 32, H // 4, W // 4, 64, 64
 d1.ksize, d1.stride, d1.pad, d1.kpad, d1.w_rows, d1.act, d1.slope = 3, 2, 1, 320, 256, 1, 0.1
+d0.variant = VARIANT
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 lib.y5_focus_conv2_f16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
 lib.y5_last_error.restype = C.c_char_p
@@ -36,8 +39,14 @@ for _ in range(20):
     lib.y5_focus_conv2_f16(C.byref(d0), C.byref(d1), st)
 e1.record(); torch.cuda.synchronize()
 print('%.1f us per launch' % (e0.elapsed_time(e1) / 20 * 1e3))
-if not hasattr(lib, 'y5_debug_stamps_stem2'):
-    sys.exit(0)  # the production library: launch time only
+if not hasattr(lib, 'y5_debug_stamps_stem2'):  # the production library: launch time, and the variants agree
+    got = y.clone()
+    y.zero_()
+    d0.variant = 0
+    assert lib.y5_focus_conv2_f16(C.byref(d0), C.byref(d1), st) == 0, lib.y5_last_error()
+    torch.cuda.synchronize()
+    print('variant %d == variant 0: %s (|y| mean %.3f)' % (VARIANT, bool(torch.equal(got, y)), float(y.float().abs().mean())))
+    sys.exit(0)
 buf = np.zeros((256 * 8, 8), dtype=np.uint64)
 assert lib.y5_debug_stamps_stem2(buf.ctypes.data_as(C.c_void_p), buf.size) == 0
 s = buf[buf[:, 7] > 0].astype(np.float64)

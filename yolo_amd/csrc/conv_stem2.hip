@@ -67,7 +67,7 @@ __device__ unsigned long long y5_stem2_stamp_buf[256 * 8 * 8];
 #define STEM_STAMP(i)
 #endif
 
-template <int F0, int F1>
+template <int F0, int F1, bool PIPE>
 __global__ __launch_bounds__(NTH) void stem2_kernel(const StemArgs a) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int t = threadIdx.x, lane = t & 63, lr = lane & 31, lh = lane >> 5;
@@ -224,24 +224,19 @@ __global__ __launch_bounds__(NTH) void stem2_kernel(const StemArgs a) {
 #ifdef Y5_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
 #endif
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the first patch
-    for (int tile = first; tile < last; ++tile, cur ^= 1) {
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // A: the patch is complete, the other buffers are free
-        STEM_STAMP(0)
-        if (tile + 1 < last) issue(tile + 1, cur ^ 1);  // that buffer was last read by layer 0 of tile - 1
+    auto do_l0 = [&](int tile, int buf) {  // layer 0 of a tile: patch[buf] -> planes[buf]
         locate(tile);
-        const unsigned char* patch = smem + PATCH0 + cur * PATCH_BYTES;
-        unsigned char* planes = smem + PLANES0 + cur * PLANES_BYTES;
+        const unsigned char* patch = smem + PATCH0 + buf * PATCH_BYTES;
+        unsigned char* planes = smem + PLANES0 + buf * PLANES_BYTES;
         const int zmask = (ty0 == 0 ? 1 : 0) | (tx0 == 0 ? 2 : 0);  // rows / columns outside layer 0's output: layer 1's zero padding
-        STEM_STAMP(4)
-        // ---- layer 0: straight-line code per wave class, so that a group's multiplies overlap the previous group's post-ops
+        // straight-line code per wave class, so that a group's multiplies overlap the previous group's post-ops
         const bool full = wave + NWC * (NU - 1) < NT0;
         if (full) layer0(std::integral_constant<int, NU>{}, patch, planes, zmask);
         else layer0(std::integral_constant<int, NU - 1>{}, patch, planes, zmask);
-        STEM_STAMP(1)
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // B: the planes are complete
-        STEM_STAMP(2)
-        // ---- layer 1
+    };
+    auto do_l1 = [&](int tile, int buf, bool wait_copies) {  // layer 1 of a tile from planes[buf], and its stores
+        locate(tile);
+        const unsigned char* planes = smem + PLANES0 + buf * PLANES_BYTES;
         f32x16 acc = zero16();
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
@@ -251,10 +246,49 @@ __global__ __launch_bounds__(NTH) void stem2_kernel(const StemArgs a) {
         f16x8 lo, hi;
         finish<F1>(acc, prm + 3 * C0, C1, mt1 * 32 + 16 * lh, a.slope1, negzero, lo, hi);
         f16* yp = a.y + ((size_t)(tb * a.Ho + ty0 + r1) * a.Wo + tx0 + c1) * a.y_ld + mt1 * 32 + 16 * lh;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile's patch pieces, issued at the top of this tile
+        if (wait_copies) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next patch's pieces, issued most of a tile ago; own stores are never waited for here
         *reinterpret_cast<f16x8*>(yp) = lo;
         *reinterpret_cast<f16x8*>(yp + 8) = hi;
-        STEM_STAMP(3)
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the first patch
+    if constexpr (PIPE) {
+        // Software pipeline over the tiles with ONE barrier per tile: between two barriers every wave does layer 0 of tile i
+        // (patch[cur] -> planes[cur]) and layer 1 of tile i - 1 (planes[cur ^ 1]) - waves 0-3 in that order, waves 4-7 in the
+        // other.  Waves w and w + 4 share a SIMD: one multiplies layer 1 while the other runs layer 0's mix of multiplies and
+        // post-ops, where in tile-by-tile order both are always in the same phase and matrix pipe and VALU take turns.
+        const bool l1_first = wave >= NWC / 2;
+        for (int tile = first; tile <= last; ++tile, cur ^= 1) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // patch[cur] and planes[cur ^ 1] complete, patch[cur ^ 1] and planes[cur] free
+            STEM_STAMP(0)
+            if (tile + 1 < last) issue(tile + 1, cur ^ 1);
+            STEM_STAMP(4)
+            if (!l1_first) {
+                if (tile < last) do_l0(tile, cur);
+                STEM_STAMP(1)
+                if (tile > first) do_l1(tile - 1, cur ^ 1, true);
+                STEM_STAMP(3)
+            } else {
+                if (tile > first) do_l1(tile - 1, cur ^ 1, false);
+                STEM_STAMP(3)
+                if (tile < last) do_l0(tile, cur);
+                STEM_STAMP(1)
+            }
+            // the pieces of the next patch must have landed before the next barrier: waves that ran layer 1 last waited before its stores
+            if (l1_first || tile == first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    } else {
+        for (int tile = first; tile < last; ++tile, cur ^= 1) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // A: the patch is complete, the other buffers are free
+            STEM_STAMP(0)
+            if (tile + 1 < last) issue(tile + 1, cur ^ 1);  // that buffer was last read by layer 0 of tile - 1
+            STEM_STAMP(4)
+            do_l0(tile, cur);
+            STEM_STAMP(1)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // B: the planes are complete
+            STEM_STAMP(2)
+            do_l1(tile, cur, true);
+            STEM_STAMP(3)
+        }
     }
 #ifdef Y5_STAMPS
     if (lane == 0 && blockIdx.x < 256) {
@@ -277,16 +311,16 @@ int cu_count() {  // compute units of the current device (one persistent workgro
     return n;
 }
 
-template <int F0, int F1>
+template <int F0, int F1, bool PIPE>
 int launch(const StemArgs& a, hipStream_t s) {
     static std::atomic<unsigned long long> attr_set{0};
     const unsigned long long bit = 1ull << y5_current_device();
     if (!(attr_set.load() & bit)) {
-        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stem2_kernel<F0, F1>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stem2_kernel<F0, F1, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         attr_set.fetch_or(bit);
     }
     const int cus = cu_count();
-    hipLaunchKernelGGL((stem2_kernel<F0, F1>), dim3((unsigned)(a.ntiles < cus ? a.ntiles : cus)), dim3(NTH), (size_t)SMEM, s, a);
+    hipLaunchKernelGGL((stem2_kernel<F0, F1, PIPE>), dim3((unsigned)(a.ntiles < cus ? a.ntiles : cus)), dim3(NTH), (size_t)SMEM, s, a);
     Y5_LAUNCH_CHECK("stem2_kernel");
     return Y5_OK;
 }
@@ -336,7 +370,8 @@ int y5_launch_focus_conv2(const y5_conv_desc& f, const y5_conv_desc& g, hipStrea
     a.slope0 = f.act == Y5_ACT_LEAKY ? f.slope : 1.f;
     a.slope1 = g.act == Y5_ACT_LEAKY ? g.slope : 1.f;
     const int f0 = (f.bias ? 1 : 0) | (f.scale ? 2 : 0), f1 = (g.bias ? 1 : 0) | (g.scale ? 2 : 0);
-    if (f0 == 1 && f1 == 1) return launch<1, 1>(a, s);
-    if (f0 == 2 && f1 == 2) return launch<2, 2>(a, s);
+    Y5_REQUIRE(f.variant == 0 || f.variant == 1, "focus_conv2: variant %d (0: tile by tile, 1: layer 1 of a tile beside layer 0 of the next)", f.variant);
+    if (f0 == 1 && f1 == 1) return f.variant ? launch<1, 1, true>(a, s) : launch<1, 1, false>(a, s);
+    if (f0 == 2 && f1 == 2) return f.variant ? launch<2, 2, true>(a, s) : launch<2, 2, false>(a, s);
     return y5_fail(Y5_EINVAL, "focus_conv2: compiled for bias-only layers (fused model) or scale+shift-only layers (BatchNorm), got %d / %d", f0, f1);
 }

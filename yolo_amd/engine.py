@@ -570,12 +570,13 @@ class Plan:
             defs, self._defer = self._defer, None
         (t0, d0, _), (t1, d1, _) = defs
         stream = _lib.current_stream()
+        d0.variant = 1  # the software-pipelined order (layer 1 of a tile beside layer 0 of the next) unless the tuner measures otherwise
         fused = self.lib.y5_focus_conv2_f16(C.byref(d0), C.byref(d1), stream) == 0
         d1.variant = self._tune(d1, mid)
         two_ms = _TUNED_MS.get(self._last_key, float('inf'))
         if fused and os.environ.get('Y5_AUTOTUNE', '1') != '0':
             key = ('stem2', B, H, W, out1.ld, bool(d0.bias), bool(d1.bias))
-            if key not in _TUNED:
+            if key not in _TUNED:  # 0: two kernels, 1 + v: one kernel, variant v
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
                 def timed(fn, n=8):
@@ -586,14 +587,19 @@ class Plan:
                     e1.record()
                     e1.synchronize()
                     return e0.elapsed_time(e1) / n
-                focus_ms = timed(lambda: self.lib.y5_focus_conv_f16(C.byref(d0), stream))
-                one_ms = timed(lambda: self.lib.y5_focus_conv2_f16(C.byref(d0), C.byref(d1), stream))
-                _TUNED[key], _TUNED_MS[key] = int(one_ms < focus_ms + two_ms), min(one_ms, focus_ms + two_ms)
-            fused = bool(_TUNED[key])
+
+                def one(v):
+                    d0.variant = v
+                    return timed(lambda: self.lib.y5_focus_conv2_f16(C.byref(d0), C.byref(d1), stream))
+                ms = [timed(lambda: self.lib.y5_focus_conv_f16(C.byref(d0), stream)) + two_ms, one(0), one(1)]
+                best = min(range(3), key=lambda i: ms[i])
+                _TUNED[key], _TUNED_MS[key] = best, ms[best]
+            fused = _TUNED[key] > 0
+            d0.variant = max(int(_TUNED[key]) - 1, 0)
         if fused:
             del self.keep[keep_n]  # the tensor between the layers: not needed (the packed weights behind it are)
             _lib.check(self.lib.y5_plan_add_focus_conv2(self.handle, C.byref(d0), C.byref(d1)))
-            self.labels.append('%s -> %s, one kernel' % (t0, t1))
+            self.labels.append('%s -> %s, one kernel v%d' % (t0, t1, d0.variant))
             return
         _lib.check(self.lib.y5_plan_add_focus_conv(self.handle, C.byref(d0)))
         self.labels.append(t0)
