@@ -170,7 +170,10 @@ int y5_focus_conv_f16(const y5_conv_desc* d, y5_stream_t stream);
  * conv: the second layer's descriptor (3x3, stride 2, 32 -> 64 channels, input = the first layer's output; x ignored) with
  * conv.ho % 8 == 0 and conv.wo % 16 == 0.  Both layers either bias-only (fused model) or scale + shift only (BatchNorm).
  * Values: for bias-only layers bit-identical to y5_focus_conv_f16 followed by y5_conv_f16's persistent stride-2 variant
- * (same summation order); with scale + shift the affine step is one fused multiply-add (isolated values one fp16 step apart). */
+ * (same summation order); with scale + shift the affine step is one fused multiply-add (isolated values one fp16 step apart).
+ * focus->variant chooses the schedule, not the arithmetic (both give the same bits): 0 = tile by tile, 1 = the second layer
+ * of a tile beside the first layer of the next tile (one barrier per tile); other values are Y5_EINVAL.  conv->variant is
+ * ignored. */
 int y5_focus_conv2_f16(const y5_conv_desc* focus, const y5_conv_desc* conv, y5_stream_t stream);
 
 /* Image pre-processing on the device, the step before the path: img.half() followed by img /= 255.0
