@@ -65,20 +65,31 @@ __global__ __launch_bounds__(NTH) void conv_c64_kernel(const C64Args a, const in
     const int first = (int)((long long)g * a.ntiles / nwg), last = (int)((long long)(g + 1) * a.ntiles / nwg);
 
     // the 3x3 weights (row i = output channel (i & 32) + perm(i & 31)) and the per-channel parameters, once
-    for (int i = t; i < C * (9 * C / 8); i += NTH) {
-        const int row = i / (9 * C / 8), sl = i - row * (9 * C / 8);
-        *reinterpret_cast<f16x8*>(smem + W10 + row * W1ROW + sl * 16) =
-            *reinterpret_cast<const f16x8*>(a.w1 + (size_t)((row & 32) + perm_row(row & 31)) * a.w1_ld + sl * 8);
+    if (wave < NWC) {
+        // The compute waves stage the 3x3 weights and the per-channel parameters (the loader wave goes straight to the first
+        // tile's copies).  All of a thread's loads are issued before the first is waited for: as a load -> store loop the
+        // staging was eight dependent round trips to L2 / the Infinity Cache at the start of every launch, and the six
+        // parameter vectors another four.
+        constexpr int SLOTS = C * (9 * C / 8), ROUNDS = SLOTS / NTHC;
+        static_assert(SLOTS % NTHC == 0 && 6 * C <= NTHC, "whole rounds of the compute waves");
+        f16x8 stage[ROUNDS];
+#pragma unroll
+        for (int j = 0; j < ROUNDS; ++j) {
+            const int i = t + j * NTHC, row = i / (9 * C / 8), sl = i - row * (9 * C / 8);
+            stage[j] = *reinterpret_cast<const f16x8*>(a.w1 + (size_t)((row & 32) + perm_row(row & 31)) * a.w1_ld + sl * 8);
+        }
+        // [b1 | s1 | h1 | b2 | s2 | h2][C]: one value per thread
+        const int sel = t / C, ch = t - sel * C;
+        const float* src = sel == 0 ? a.b1 : sel == 1 ? a.s1 : sel == 2 ? (a.s1 ? a.h1 : nullptr) : sel == 3 ? a.b2 : sel == 4 ? a.s2 : (a.s2 ? a.h2 : nullptr);
+        const float pv = (t < 6 * C && src) ? src[ch] : (sel == 1 || sel == 4) ? 1.f : 0.f;
+#pragma unroll
+        for (int j = 0; j < ROUNDS; ++j) {
+            const int i = t + j * NTHC, row = i / (9 * C / 8), sl = i - row * (9 * C / 8);
+            *reinterpret_cast<f16x8*>(smem + W10 + row * W1ROW + sl * 16) = stage[j];
+        }
+        if (t < 6 * C) reinterpret_cast<float*>(smem + PRM0)[t] = pv;
     }
     float* prm = reinterpret_cast<float*>(smem + PRM0);
-    for (int i = t; i < C; i += NTH) {
-        prm[i] = a.b1 ? a.b1[i] : 0.f;
-        prm[C + i] = a.s1 ? a.s1[i] : 1.f;
-        prm[2 * C + i] = a.s1 ? a.h1[i] : 0.f;
-        prm[3 * C + i] = a.b2 ? a.b2[i] : 0.f;
-        prm[4 * C + i] = a.s2 ? a.s2[i] : 1.f;
-        prm[5 * C + i] = a.s2 ? a.h2[i] : 0.f;
-    }
 
     int tb, ty0, tx0;
     auto locate = [&](int tile) {

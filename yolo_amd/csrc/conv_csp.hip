@@ -80,11 +80,27 @@ __device__ __forceinline__ f16x8 load_wfrag(const CspStage& st, int row0, int k0
     return *reinterpret_cast<const f16x8*>(st.w + (size_t)(row0 + perm_row(lr)) * st.w_ld + k0 + 8 * lh);
 }
 
-__device__ __forceinline__ void stage_params(float* prm, const CspStage& st, int n, int t) {
-    for (int i = t; i < n; i += NTHREADS) {
-        prm[i] = st.bias ? st.bias[i] : 0.f;
-        prm[n + i] = st.scale ? st.scale[i] : 1.f;
-        prm[2 * n + i] = st.scale ? st.shift[i] : 0.f;
+// Per-channel parameters of a stage with n <= NTHREADS channels: fetched by one call, stored by another, so that the loads
+// of all stages (and of the weights) are in flight together instead of one round trip after the other.
+struct StageParams {
+    float b, s, h;
+};
+__device__ __forceinline__ StageParams fetch_params(const CspStage& st, int n, int t) {
+    StageParams v = {0.f, 1.f, 0.f};
+    if (t < n) {
+        if (st.bias) v.b = st.bias[t];
+        if (st.scale) {
+            v.s = st.scale[t];
+            v.h = st.shift[t];
+        }
+    }
+    return v;
+}
+__device__ __forceinline__ void store_params(float* prm, const StageParams& v, int n, int t) {
+    if (t < n) {
+        prm[t] = v.b;
+        prm[n + t] = v.s;
+        prm[2 * n + t] = v.h;
     }
 }
 
@@ -110,39 +126,8 @@ __global__ __launch_bounds__(NTHREADS) void csp1_kernel(const CspArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
 
     float* prm = reinterpret_cast<float*>(smem + Cfg::PRM0);
-    stage_params(prm + Cfg::P1, a.s1, CH, t);
-    stage_params(prm + Cfg::P2, a.s2, CH, t);
-    stage_params(prm + Cfg::PM1, a.sm1, CH, t);
-    stage_params(prm + Cfg::PM2, a.sm2, CH, t);
-    stage_params(prm + Cfg::P3, a.s3, CH, t);
-    stage_params(prm + Cfg::P4, a.s4, C2, t);
     float negzero;
     asm volatile("v_mov_b32 %0, 0x80000000" : "=v"(negzero));  // opaque to the optimiser: x*s + (-0) keeps the sign of a zero product
-
-    // ---- weights.  In registers for the whole kernel: this wave's half of [cv1 | cv2], m.cv1, cv3.  In LDS: m.cv2, cv4.
-    const int mt1 = wave & 1;
-    f16x8 w12[K1], wm1[KH], w3[KH];
-#pragma unroll
-    for (int ks = 0; ks < K1; ++ks) w12[ks] = load_wfrag(mt1 ? a.s2 : a.s1, 0, ks * 16, lr, lh);
-#pragma unroll
-    for (int ks = 0; ks < KH; ++ks) wm1[ks] = load_wfrag(a.sm1, 0, ks * 16, lr, lh);
-#pragma unroll
-    for (int ks = 0; ks < KH; ++ks) w3[ks] = load_wfrag(a.s3, 0, ks * 16, lr, lh);
-    for (int i = t; i < C2 * 8; i += NTHREADS) {
-        const int row = i >> 3, sl = i & 7;
-        *reinterpret_cast<f16x8*>(smem + Cfg::W40 + row * 128 + ((sl ^ ((row >> 1) & 7)) << 4)) =
-            *reinterpret_cast<const f16x8*>(a.s4.w + (size_t)((row & 32) + perm_row(row & 31)) * a.s4.w_ld + sl * 8);
-    }
-    for (int i = t; i < CH * (9 * CH / 8); i += NTHREADS) {
-        const int row = i / (9 * CH / 8), sl = i - row * (9 * CH / 8);
-        *reinterpret_cast<f16x8*>(smem + Cfg::WM20 + row * Cfg::WM2ROW + sl * 16) =
-            *reinterpret_cast<const f16x8*>(a.sm2.w + (size_t)perm_row(row) * a.sm2.w_ld + sl * 8);
-    }
-    const unsigned char* w4p = smem + Cfg::W40 + lr * 128;
-    const unsigned char* wm2p = smem + Cfg::WM20 + lr * Cfg::WM2ROW + lh * 16;
-    int uoff[9];  // byte offset in u of this lane's K-step-0 fragment per tap (K-step 1 is the slot two further: offset ^ 32)
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) uoff[tap] = trow_off((wave + tap / 3) * HW + lr + tap % 3, lh);
 
     // ---- the wave's share of the input copy: piece d = wave + 8j is 1 KiB of the staged tile, 16-byte slot d*64 + lane
     unsigned rc[DMA_PER_WAVE];  // halo row | halo column << 8 | nothing to copy << 20
@@ -183,8 +168,57 @@ __global__ __launch_bounds__(NTHREADS) void csp1_kernel(const CspArgs a) {
             dma16_buf(xr, ok ? (unsigned)(base + rel[j]) : Y5_BUF_OOB, (unsigned)(buf * X_BYTES + (wave + NWAVE * j) * 1024));
         }
     };
-
+    // The first tile's copies go out before anything else is fetched, and everything the workgroup stages once is
+    // requested before any of it is waited for (as load -> store loops the parameters and the LDS-resident weights were
+    // ten dependent round trips to L2 / the Infinity Cache in front of the first copy).
     if (first < last) issue(first, 0);
+
+    // ---- weights.  In registers for the whole kernel: this wave's half of [cv1 | cv2], m.cv1, cv3.  In LDS: m.cv2, cv4.
+    const int mt1 = wave & 1;
+    f16x8 w12[K1], wm1[KH], w3[KH];
+#pragma unroll
+    for (int ks = 0; ks < K1; ++ks) w12[ks] = load_wfrag(mt1 ? a.s2 : a.s1, 0, ks * 16, lr, lh);
+#pragma unroll
+    for (int ks = 0; ks < KH; ++ks) wm1[ks] = load_wfrag(a.sm1, 0, ks * 16, lr, lh);
+#pragma unroll
+    for (int ks = 0; ks < KH; ++ks) w3[ks] = load_wfrag(a.s3, 0, ks * 16, lr, lh);
+    {
+        static_assert(CH <= NTHREADS && C2 <= NTHREADS && C2 * 8 <= NTHREADS, "one parameter and one cv4 slot per thread");
+        const StageParams q1 = fetch_params(a.s1, CH, t), q2 = fetch_params(a.s2, CH, t), qm1 = fetch_params(a.sm1, CH, t),
+                          qm2 = fetch_params(a.sm2, CH, t), q3 = fetch_params(a.s3, CH, t), q4 = fetch_params(a.s4, C2, t);
+        constexpr int M2_SLOTS = CH * (9 * CH / 8), M2_ROUNDS = (M2_SLOTS + NTHREADS - 1) / NTHREADS;
+        f16x8 s4v = {}, m2v[M2_ROUNDS];
+        if (t < C2 * 8) {
+            const int row = t >> 3, sl = t & 7;
+            s4v = *reinterpret_cast<const f16x8*>(a.s4.w + (size_t)((row & 32) + perm_row(row & 31)) * a.s4.w_ld + sl * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < M2_ROUNDS; ++j) {
+            const int i = t + j * NTHREADS, row = i / (9 * CH / 8), sl = i - row * (9 * CH / 8);
+            if (i < M2_SLOTS) m2v[j] = *reinterpret_cast<const f16x8*>(a.sm2.w + (size_t)perm_row(row) * a.sm2.w_ld + sl * 8);
+        }
+        store_params(prm + Cfg::P1, q1, CH, t);
+        store_params(prm + Cfg::P2, q2, CH, t);
+        store_params(prm + Cfg::PM1, qm1, CH, t);
+        store_params(prm + Cfg::PM2, qm2, CH, t);
+        store_params(prm + Cfg::P3, q3, CH, t);
+        store_params(prm + Cfg::P4, q4, C2, t);
+        if (t < C2 * 8) {
+            const int row = t >> 3, sl = t & 7;
+            *reinterpret_cast<f16x8*>(smem + Cfg::W40 + row * 128 + ((sl ^ ((row >> 1) & 7)) << 4)) = s4v;
+        }
+#pragma unroll
+        for (int j = 0; j < M2_ROUNDS; ++j) {
+            const int i = t + j * NTHREADS, row = i / (9 * CH / 8), sl = i - row * (9 * CH / 8);
+            if (i < M2_SLOTS) *reinterpret_cast<f16x8*>(smem + Cfg::WM20 + row * Cfg::WM2ROW + sl * 16) = m2v[j];
+        }
+    }
+    const unsigned char* w4p = smem + Cfg::W40 + lr * 128;
+    const unsigned char* wm2p = smem + Cfg::WM20 + lr * Cfg::WM2ROW + lh * 16;
+    int uoff[9];  // byte offset in u of this lane's K-step-0 fragment per tap (K-step 1 is the slot two further: offset ^ 32)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) uoff[tap] = trow_off((wave + tap / 3) * HW + lr + tap % 3, lh);
+
     int cur = 0;
 #ifdef Y5_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();

@@ -57,17 +57,17 @@ __global__ __launch_bounds__(NTH) void conv_p1x1_kernel(const P1Args a) {
     const int first = 0, last = (run1 - run0 + Cfg::TP - 1) / Cfg::TP;
 
     float* prm = reinterpret_cast<float*>(smem + Cfg::PRM0);
-    for (int i = t; i < Cfg::CO; i += NTH) {
-        prm[i] = a.bias ? a.bias[i] : 0.f;
-        prm[Cfg::CO + i] = a.scale ? a.scale[i] : 1.f;
-        prm[2 * Cfg::CO + i] = a.scale ? a.shift[i] : 0.f;
+    static_assert(Cfg::CO <= NTH, "one channel's parameters per thread");
+    float pv[3] = {0.f, 1.f, 0.f};  // fetched here, stored once the weights have landed: one round trip for everything
+    if (t < Cfg::CO) {
+        if (a.bias) pv[0] = a.bias[t];
+        if (a.scale) {
+            pv[1] = a.scale[t];
+            pv[2] = a.shift[t];
+        }
     }
 
     const int mt = wave % NCW, pg = wave / NCW;  // output channels [32 mt, +32); pixels [32 NT pg, +32 NT) of the tile
-    f16x8 wf[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) wf[ks] = *reinterpret_cast<const f16x8*>(a.w + (size_t)(mt * 32 + perm_row(lr)) * a.w_ld + ks * 16 + lh * 8);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // from here on the only loads in flight are the copies counted below
 
     // ---------------------------------------------------------------------- the copies: wave w issues pieces w, w + 8, ...
     const i32x4 xr = make_buf(a.x, a.x_bytes);
@@ -95,14 +95,22 @@ __global__ __launch_bounds__(NTH) void conv_p1x1_kernel(const P1Args a) {
     float negzero;
     asm volatile("v_mov_b32 %0, 0x80000000" : "=v"(negzero));
 
-    // two tiles ahead: when tile i's pieces are waited for, those of tile i + 1 (the newest MYP) may still be in flight
+    // The first tile's pieces go out before the weights are fetched, so that both arrive in one round trip (parameters,
+    // then weights, then copies cost the launch three).
     if (first < last) issue(first, 0);
-    if (first + 1 < last) {
-        issue(first + 1, 1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MYP) : "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    f16x8 wf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) wf[ks] = *reinterpret_cast<const f16x8*>(a.w + (size_t)(mt * 32 + perm_row(lr)) * a.w_ld + ks * 16 + lh * 8);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // from here on the only loads in flight are the copies counted below
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(wf[ks]));  // in registers: nothing in the tile loop waits for them
+    if (t < Cfg::CO) {
+        prm[t] = pv[0];
+        prm[Cfg::CO + t] = pv[1];
+        prm[2 * Cfg::CO + t] = pv[2];
     }
+    // two tiles ahead: when tile i's pieces are waited for, those of tile i + 1 (the newest MYP) may still be in flight
+    if (first + 1 < last) issue(first + 1, 1);
     Prm16<F> q;
     bool have_prm = false;
     int buf = 0;
@@ -191,26 +199,25 @@ __global__ __launch_bounds__(NTH) void conv_p1x1_chain_kernel(const P1ChainArgs 
 
     float* prm = reinterpret_cast<float*>(smem + Cfg::PRM0);
     float* prm2 = prm + 3 * Cfg::CO;
-    for (int i = t; i < Cfg::CO; i += NTH) {
-        prm[i] = a.bias ? a.bias[i] : 0.f;
-        prm[Cfg::CO + i] = a.scale ? a.scale[i] : 1.f;
-        prm[2 * Cfg::CO + i] = a.scale ? a.shift[i] : 0.f;
+    static_assert(Cfg::CO <= NTH && Cfg::CO2 <= NTH, "one channel's parameters per thread");
+    float pv[3] = {0.f, 1.f, 0.f}, pv2[3] = {0.f, 1.f, 0.f};  // fetched here, stored once the weights have landed
+    if (t < Cfg::CO) {
+        if (a.bias) pv[0] = a.bias[t];
+        if (a.scale) {
+            pv[1] = a.scale[t];
+            pv[2] = a.shift[t];
+        }
     }
-    for (int i = t; i < Cfg::CO2; i += NTH) {
-        prm2[i] = c.bias2 ? c.bias2[i] : 0.f;
-        prm2[Cfg::CO2 + i] = c.scale2 ? c.scale2[i] : 1.f;
-        prm2[2 * Cfg::CO2 + i] = c.scale2 ? c.shift2[i] : 0.f;
+    if (t < Cfg::CO2) {
+        if (c.bias2) pv2[0] = c.bias2[t];
+        if (c.scale2) {
+            pv2[1] = c.scale2[t];
+            pv2[2] = c.shift2[t];
+        }
     }
 
     const int mt = wave % NCW, pg = wave / NCW;      // first stage: output channels [32 mt, +32), pixels [32 NT pg, +32 NT)
     const int mt2 = wave % NCW2, pg2 = wave / NCW2;  // second stage: output channels [32 mt2, +32), pixels [32 pg2, +32)
-    f16x8 wf[KS], wg[KS2];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) wf[ks] = *reinterpret_cast<const f16x8*>(a.w + (size_t)(mt * 32 + perm_row(lr)) * a.w_ld + ks * 16 + lh * 8);
-#pragma unroll
-    for (int ks = 0; ks < KS2; ++ks) wg[ks] = *reinterpret_cast<const f16x8*>(c.w2 + (size_t)(mt2 * 32 + perm_row(lr)) * c.w2_ld + ks * 16 + lh * 8);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // from here on the only loads in flight are the copies counted below
-
     const i32x4 xr = make_buf(a.x, a.x_bytes);
     int rel[MYP], cpx[MYP];
 #pragma unroll
@@ -239,13 +246,29 @@ __global__ __launch_bounds__(NTH) void conv_p1x1_chain_kernel(const P1ChainArgs 
     float negzero;
     asm volatile("v_mov_b32 %0, 0x80000000" : "=v"(negzero));
 
+    // the first tile's pieces go out before the weights are fetched: one round trip for parameters, weights and copies
     if (first < last) issue(first, 0);
-    if (first + 1 < last) {
-        issue(first + 1, 1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MYP) : "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    f16x8 wf[KS], wg[KS2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) wf[ks] = *reinterpret_cast<const f16x8*>(a.w + (size_t)(mt * 32 + perm_row(lr)) * a.w_ld + ks * 16 + lh * 8);
+#pragma unroll
+    for (int ks = 0; ks < KS2; ++ks) wg[ks] = *reinterpret_cast<const f16x8*>(c.w2 + (size_t)(mt2 * 32 + perm_row(lr)) * c.w2_ld + ks * 16 + lh * 8);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // from here on the only loads in flight are the copies counted below
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(wf[ks]));  // in registers: nothing in the tile loop waits for them
+#pragma unroll
+    for (int ks = 0; ks < KS2; ++ks) asm volatile("" : "+v"(wg[ks]));
+    if (t < Cfg::CO) {
+        prm[t] = pv[0];
+        prm[Cfg::CO + t] = pv[1];
+        prm[2 * Cfg::CO + t] = pv[2];
     }
+    if (t < Cfg::CO2) {
+        prm2[t] = pv2[0];
+        prm2[Cfg::CO2 + t] = pv2[1];
+        prm2[2 * Cfg::CO2 + t] = pv2[2];
+    }
+    if (first + 1 < last) issue(first + 1, 1);
     // The second stage runs one tile behind the first (two T buffers): one barrier per tile orders both, and the waves have
     // the second stage's products of tile i - 1 to issue beside the first stage's of tile i.
     auto second = [&](int tile) {

@@ -54,10 +54,14 @@ __global__ __launch_bounds__(NTH) void conv_s2c64_kernel(const S2Args a) {
     const int first = (int)((long long)g * a.ntiles / nwg), last = (int)((long long)(g + 1) * a.ntiles / nwg);
 
     float* prm = reinterpret_cast<float*>(smem + PRM0);
-    for (int i = t; i < CO; i += NTH) {
-        prm[i] = a.bias ? a.bias[i] : 0.f;
-        prm[CO + i] = a.scale ? a.scale[i] : 1.f;
-        prm[2 * CO + i] = a.scale ? a.shift[i] : 0.f;
+    static_assert(CO <= NTH, "one channel's parameters per thread");
+    float pv[3] = {0.f, 1.f, 0.f};  // fetched here, stored once the weights have landed: one round trip for everything
+    if (t < CO) {
+        if (a.bias) pv[0] = a.bias[t];
+        if (a.scale) {
+            pv[1] = a.scale[t];
+            pv[2] = a.shift[t];
+        }
     }
 
     int tb, ty0, tx0;  // image and first output pixel of a tile
@@ -71,10 +75,6 @@ __global__ __launch_bounds__(NTH) void conv_s2c64_kernel(const S2Args a) {
 
     const int nt = wave >> 2, mt = wave & 3;  // output rows 2 nt, 2 nt + 1 of the tile; output channels [32 mt, +32)
     const int r = 2 * nt + (lr >> 4), c = lr & 15;
-    f16x8 wf[9 * CI / 16];
-#pragma unroll
-    for (int ks = 0; ks < 9 * CI / 16; ++ks) wf[ks] = *reinterpret_cast<const f16x8*>(a.w + (size_t)(mt * 32 + perm_row(lr)) * a.w_ld + ks * 16 + lh * 8);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // from here on the only loads in flight are the copies counted below
 
     // ---------------------------------------------------------------------- the copies: wave w issues pieces w, w + 8, ...
     const i32x4 xr = make_buf(a.x, a.x_bytes);
@@ -109,14 +109,22 @@ __global__ __launch_bounds__(NTH) void conv_s2c64_kernel(const S2Args a) {
     float negzero;
     asm volatile("v_mov_b32 %0, 0x80000000" : "=v"(negzero));
 
-    // two tiles ahead: when tile i's pieces are waited for, those of tile i + 1 (the newest MYP) may still be in flight
+    // The first tile's pieces go out before the weights are fetched, so that both arrive in one round trip (the weights
+    // first, then the copies, cost the launch two).
     if (first < last) issue(first, 0);
-    if (first + 1 < last) {
-        issue(first + 1, 1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MYP) : "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    f16x8 wf[9 * CI / 16];
+#pragma unroll
+    for (int ks = 0; ks < 9 * CI / 16; ++ks) wf[ks] = *reinterpret_cast<const f16x8*>(a.w + (size_t)(mt * 32 + perm_row(lr)) * a.w_ld + ks * 16 + lh * 8);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // from here on the only loads in flight are the copies counted below
+#pragma unroll
+    for (int ks = 0; ks < 9 * CI / 16; ++ks) asm volatile("" : "+v"(wf[ks]));  // in registers: nothing in the tile loop waits for them
+    if (t < CO) {
+        prm[t] = pv[0];
+        prm[CO + t] = pv[1];
+        prm[2 * CO + t] = pv[2];
     }
+    // two tiles ahead: when tile i's pieces are waited for, those of tile i + 1 (the newest MYP) may still be in flight
+    if (first + 1 < last) issue(first + 1, 1);
     int buf = 0;
     for (int tile = first; tile < last; ++tile) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave's pieces of this tile have landed; tile - 1 is read

@@ -75,27 +75,6 @@ __global__ __launch_bounds__(NTH) void stem2_kernel(const StemArgs a) {
     const int nwg = gridDim.x, g = xcd_remap(blockIdx.x, nwg);
     const int first = (int)((long long)g * a.ntiles / nwg), last = (int)((long long)(g + 1) * a.ntiles / nwg);
 
-    float* prm = reinterpret_cast<float*>(smem + PRM0);  // [bias | scale | shift] of layer 0 (C0 each), then of layer 1 (C1 each)
-    for (int i = t; i < C0; i += NTH) {
-        prm[i] = a.b0 ? a.b0[i] : 0.f;
-        prm[C0 + i] = a.s0 ? a.s0[i] : 1.f;
-        prm[2 * C0 + i] = a.s0 ? a.h0[i] : 0.f;
-    }
-    for (int i = t; i < C1; i += NTH) {
-        prm[3 * C0 + i] = a.b1 ? a.b1[i] : 0.f;
-        prm[3 * C0 + C1 + i] = a.s1 ? a.s1[i] : 1.f;
-        prm[3 * C0 + 2 * C1 + i] = a.s1 ? a.h1[i] : 0.f;
-    }
-
-    // layer 0 weights: row i = output channel perm(i); k-group g = r6 * 3 + c (image row r6 of the 6x6 window, channel c)
-    // holds the 8 columns q6 (6 used) of the packed row k = (r*3 + q)*16 + (dy + 2*dx)*3 + c with r6 = 2r + dy, q6 = 2q + dx
-    f16* w0l = reinterpret_cast<f16*>(smem + W00);
-    for (int idx = t; idx < C0 * 144; idx += NTH) {
-        const int n = idx / 144, rem = idx - n * 144;
-        const int grp = rem >> 3, q6 = rem & 7, r6 = grp / 3, c = grp - 3 * r6;
-        w0l[n * W0ROW + rem] = q6 < 6 ? a.w0[(size_t)perm_row(n) * a.w0_ld + ((r6 >> 1) * 3 + (q6 >> 1)) * 16 + ((r6 & 1) + 2 * (q6 & 1)) * 3 + c] : (f16)0.f;
-    }
-
     int tb, ty0, tx0;  // image and first layer-1 output pixel of a tile
     auto locate = [&](int tile) {
         tb = (int)fdiv((unsigned)tile, a.div_tpi);
@@ -144,6 +123,41 @@ __global__ __launch_bounds__(NTH) void stem2_kernel(const StemArgs a) {
         }
     };
     if (first < last) issue(first, 0);
+
+    // ------------------------------------------------------------------ parameters and layer 0's weights -> LDS
+    // All of a thread's loads are issued (after the first patch's copies) before the first is waited for: written as
+    // load -> store loops, the staging was eleven dependent round trips to L2 / the Infinity Cache at the start of the launch.
+    float* prm = reinterpret_cast<float*>(smem + PRM0);  // [bias | scale | shift] of layer 0 (C0 each), then of layer 1 (C1 each)
+    f16* w0l = reinterpret_cast<f16*>(smem + W00);
+    {
+        static_assert(C0 <= NTH && C1 <= NTH && (C0 * 144) % NTH == 0, "one parameter per thread, whole rounds of weights");
+        float p0[3] = {0.f, 1.f, 0.f}, p1[3] = {0.f, 1.f, 0.f};
+        if (t < C0) {
+            if (a.b0) p0[0] = a.b0[t];
+            if (a.s0) { p0[1] = a.s0[t]; p0[2] = a.h0[t]; }
+        }
+        if (t < C1) {
+            if (a.b1) p1[0] = a.b1[t];
+            if (a.s1) { p1[1] = a.s1[t]; p1[2] = a.h1[t]; }
+        }
+        // layer 0 weights: row i = output channel perm(i); k-group g = r6 * 3 + c (image row r6 of the 6x6 window, channel c)
+        // holds the 8 columns q6 (6 used) of the packed row k = (r*3 + q)*16 + (dy + 2*dx)*3 + c with r6 = 2r + dy, q6 = 2q + dx
+        constexpr int ROUNDS = C0 * 144 / NTH;
+        f16 wv[ROUNDS];
+#pragma unroll
+        for (int j = 0; j < ROUNDS; ++j) {
+            const int idx = t + j * NTH, n = idx / 144, rem = idx - n * 144;
+            const int grp = rem >> 3, q6 = rem & 7, r6 = grp / 3, c = grp - 3 * r6;
+            wv[j] = q6 < 6 ? a.w0[(size_t)perm_row(n) * a.w0_ld + ((r6 >> 1) * 3 + (q6 >> 1)) * 16 + ((r6 & 1) + 2 * (q6 & 1)) * 3 + c] : (f16)0.f;
+        }
+        if (t < C0) { prm[t] = p0[0]; prm[C0 + t] = p0[1]; prm[2 * C0 + t] = p0[2]; }
+        if (t < C1) { prm[3 * C0 + t] = p1[0]; prm[3 * C0 + C1 + t] = p1[1]; prm[3 * C0 + 2 * C1 + t] = p1[2]; }
+#pragma unroll
+        for (int j = 0; j < ROUNDS; ++j) {
+            const int idx = t + j * NTH, n = idx / 144, rem = idx - n * 144;
+            w0l[n * W0ROW + rem] = wv[j];
+        }
+    }
 
     // ---------------------------------------------------------------------- weights and per-lane offsets
     __syncthreads();
