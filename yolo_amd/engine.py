@@ -27,6 +27,38 @@ from yolo_amd import _lib
 from yolo_amd.utils.torch_utils import bn_affine
 
 _DISABLED = [0]
+def _fastest(candidates, launch):
+    """The fastest of `candidates` (variant ids) and its milliseconds per launch.  launch(v) issues one launch of variant v
+    on the current stream and returns 0, or non-zero when the variant does not apply to the shape.  Every applicable
+    variant is timed over four launches; the three fastest are within timing noise of each other after that, so they are
+    timed again over twelve launches in two interleaved rounds (a clock or cache transient then hits all of them alike)
+    and each keeps its better round.  Returns (None, inf) when no candidate applies."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    timed = []
+    for v in candidates:
+        if launch(v) != 0:
+            continue
+        e0.record()
+        for _ in range(4):
+            launch(v)
+        e1.record()
+        e1.synchronize()
+        timed.append((e0.elapsed_time(e1) / 4, v))
+    if not timed:
+        return None, float('inf')
+    again = {v: float('inf') for _, v in sorted(timed)[:3]}
+    for _ in range(2):
+        for v in again:
+            e0.record()
+            for _ in range(12):
+                launch(v)
+            e1.record()
+            e1.synchronize()
+            again[v] = min(again[v], e0.elapsed_time(e1) / 12)
+    best = min(again, key=again.get)
+    return best, again[best]
+
+
 _TUNED = {}   # conv shape key -> fastest variant id, shared by all plans of the process
 _TUNED_MS = {}  # key -> milliseconds per launch of the chosen variant
 _ENGINES = weakref.WeakKeyDictionary()  # model -> Engine; kept out of the module so that deepcopy / pickle / torch.save of
@@ -393,20 +425,12 @@ class Plan:
             a.buf.uniform_(-1.0, 1.0)
             b.buf.uniform_(-1.0, 1.0)
             stream = _lib.current_stream()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            best, best_t = 0, float('inf')
-            for v in range(1, self.lib.y5_conv_cat2_num_variants() + 1):
+
+            def launch(v):
                 d.variant = v
-                if self.lib.y5_conv_cat2_f16(C.byref(d), b.ptr, b.ld, b.c_pad, stream) != 0:
-                    continue
-                e0.record()
-                for _ in range(4):
-                    self.lib.y5_conv_cat2_f16(C.byref(d), b.ptr, b.ld, b.c_pad, stream)
-                e1.record()
-                e1.synchronize()
-                if e0.elapsed_time(e1) < best_t:
-                    best, best_t = v, e0.elapsed_time(e1)
-            _TUNED[key], _TUNED_MS[key] = best, best_t / 4
+                return self.lib.y5_conv_cat2_f16(C.byref(d), b.ptr, b.ld, b.c_pad, stream)
+            best, best_ms = _fastest(range(1, self.lib.y5_conv_cat2_num_variants() + 1), launch)
+            _TUNED[key], _TUNED_MS[key] = best or 0, best_ms
         return _TUNED[key]
 
     def _emit_chain(self, defs, keep_first=0):
@@ -421,18 +445,9 @@ class Plan:
             key = ('chain', keep_first, d1.batch, d1.h, d1.w_in, d1.cin, d1.x_ld, d1.cout, d1.ksize, d1.stride, bool(d1.res), d2.cin, d2.cout, d2.y_ld)
             if key not in _TUNED and tune:
                 x1.buf.uniform_(-1.0, 1.0)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                for v in range(1, self.lib.y5_conv_chain_num_variants() + 1):
-                    if self.lib.y5_conv_chain_f16(C.byref(d1), C.byref(d2), keep_first, v, stream) != 0:
-                        continue
-                    e0.record()
-                    for _ in range(4):
-                        self.lib.y5_conv_chain_f16(C.byref(d1), C.byref(d2), keep_first, v, stream)
-                    e1.record()
-                    e1.synchronize()
-                    if e0.elapsed_time(e1) / 4 < best_ms:
-                        best, best_ms = v, e0.elapsed_time(e1) / 4
-                _TUNED[key], _TUNED_MS[key] = best, best_ms
+                best, best_ms = _fastest(range(1, self.lib.y5_conv_chain_num_variants() + 1),
+                                         lambda v: self.lib.y5_conv_chain_f16(C.byref(d1), C.byref(d2), keep_first, v, stream))
+                _TUNED[key], _TUNED_MS[key] = best or 0, best_ms
             best, best_ms = _TUNED.get(key, 0), _TUNED_MS.get(key, 0.0 if not tune else float('inf'))
         else:
             best = -1
@@ -469,33 +484,13 @@ class Plan:
             return _TUNED[key]
         x.buf.uniform_(-1.0, 1.0)
         stream = _lib.current_stream()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        timed = []
         nvar = self.lib.y5_conv_num_variants_bf16() if self.bf16 else self.lib.y5_conv_num_variants()
-        for v in range(nvar + 1):
+
+        def launch(v):
             d.variant = v
-            if self.lib.y5_conv_f16(C.byref(d), stream) != 0:
-                continue  # configuration does not apply to this shape
-            e0.record()
-            for _ in range(4):
-                self.lib.y5_conv_f16(C.byref(d), stream)
-            e1.record()
-            e1.synchronize()
-            timed.append((e0.elapsed_time(e1) / 4, v))
-        # the few fastest are within timing noise of each other after four launches: time those again, longer, in two
-        # interleaved rounds (a clock or cache transient then hits all of them alike), and keep each one's better round
-        again = {v: float('inf') for _, v in sorted(timed)[:3]}
-        for _ in range(2):
-            for v in again:
-                d.variant = v
-                e0.record()
-                for _ in range(12):
-                    self.lib.y5_conv_f16(C.byref(d), stream)
-                e1.record()
-                e1.synchronize()
-                again[v] = min(again[v], e0.elapsed_time(e1) / 12)
-        best = min(again, key=again.get)
-        best_t = again[best]
+            return self.lib.y5_conv_f16(C.byref(d), stream)
+        best, best_t = _fastest(range(nvar + 1), launch)
+        best = best or 0
         _TUNED[key] = best
         _TUNED_MS[key] = best_t
         return best
