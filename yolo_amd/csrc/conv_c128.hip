@@ -172,26 +172,11 @@ __global__ __launch_bounds__(NTH) void conv_c128_kernel(const C128Args a, const 
 #ifdef Y5_STAMPS
     unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
 #endif
-    // Everything the workgroup needs is requested before anything is waited for: the 3x3 weights into registers, the
-    // per-channel parameters, then the copies global -> LDS of the strip + halo and of the 1x1 weights.
+    // Everything the workgroup needs is requested before anything is waited for, in the order in which it is consumed
+    // LAST first: the copies global -> LDS of the strip + halo and of the 1x1 weights, the per-channel parameters, then the
+    // 3x3 weights into registers tap by tap.  Vector memory operations retire in order, so the permutation of tap 0 below
+    // can start when that tap's four loads have landed, while the later taps are still streaming in.
     const int cb = wave & 3, kh = wave >> 2;
-    // The 3x3 weights are fetched as whole 128-byte lines (a load instruction covers eight rows' 64 channels of one tap:
-    // fetched the way the matrix instruction wants them, 32 rows x 32 bytes per instruction, the loads cost the CU four times
-    // as many L2 requests and 12 k cycles to issue) and brought into fragment order through LDS below.
-    f16x8 wf[36];
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            wf[tap * 4 + j] = *reinterpret_cast<const f16x8*>(a.w1 + (size_t)(cb * 32 + 8 * j + (lane >> 3)) * a.w1_ld + tap * C + kh * 64 + (lane & 7) * 8);
-    float pv[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {  // [b1 | s1 | h1 | b2 | s2 | h2][C]
-        const int i = t + j * NTH, sel = i >> 7, ch = i & (C - 1);
-        const float* src = sel == 0 ? a.b1 : sel == 1 ? a.s1 : sel == 2 ? (a.s1 ? a.h1 : nullptr) : sel == 3 ? a.b2 : sel == 4 ? a.s2 : (a.s2 ? a.h2 : nullptr);
-        pv[j] = (i < 6 * C && src) ? src[ch] : (sel == 1 || sel == 4) ? 1.f : 0.f;
-    }
-    C128_STAMP(0)
     const i32x4 xr = make_buf(a.x, a.x_bytes);
 #pragma unroll
     for (int j = 0; j < MYP; ++j) {
@@ -210,17 +195,35 @@ __global__ __launch_bounds__(NTH) void conv_c128_kernel(const C128Args a, const 
         dma16_buf(wr, (unsigned)(((row & ~31) + perm_row(row & 31)) * (a.w2_ld * 2) + sl * 16), (unsigned)(W20 + d * 1024));
     }
     C128_STAMP(1)
+    float pv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {  // [b1 | s1 | h1 | b2 | s2 | h2][C]
+        const int i = t + j * NTH, sel = i >> 7, ch = i & (C - 1);
+        const float* src = sel == 0 ? a.b1 : sel == 1 ? a.s1 : sel == 2 ? (a.s1 ? a.h1 : nullptr) : sel == 3 ? a.b2 : sel == 4 ? a.s2 : (a.s2 ? a.h2 : nullptr);
+        pv[j] = (i < 6 * C && src) ? src[ch] : (sel == 1 || sel == 4) ? 1.f : 0.f;
+    }
+    // The 3x3 weights are fetched as whole 128-byte lines (a load instruction covers eight rows' 64 channels of one tap:
+    // fetched the way the matrix instruction wants them, 32 rows x 32 bytes per instruction, the loads cost the CU four times
+    // as many L2 requests and 12 k cycles to issue) and brought into fragment order through LDS below.
+    f16x8 wf[36];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            wf[tap * 4 + j] = *reinterpret_cast<const f16x8*>(a.w1 + (size_t)(cb * 32 + 8 * j + (lane >> 3)) * a.w1_ld + tap * C + kh * 64 + (lane & 7) * 8);
+        asm volatile("" ::: "memory");  // keep the taps in this order: the permutation below consumes them in it
+    }
+    C128_STAMP(0)
     float* prm = reinterpret_cast<float*>(smem + PRM0);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
         if (t + j * NTH < 6 * C) prm[t + j * NTH] = pv[j];
     float negzero;
     asm volatile("v_mov_b32 %0, 0x80000000" : "=v"(negzero));
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    C128_STAMP(2)
     {   // fragment order: register tap * 4 + ks of lane (lr, lh) holds channels [64 kh + 16 ks + 8 lh, +8) of row perm(lr).  Four
         // registers (one tap: 32 rows x 128 bytes) at a time through 4 KiB of this wave's own in the hand-over area, which
-        // nothing uses before the first barrier; chunk c of row r sits at slot c ^ (r & 7).
+        // nothing uses before the first barrier; chunk c of row r sits at slot c ^ (r & 7).  (The waits for the loads are the
+        // compiler's: one per tap, each for that tap's four registers only.)
         unsigned char* stg = smem + RED0 + wave * 4096;
         const int rho = perm_row(lr);
 #pragma unroll
@@ -234,6 +237,8 @@ __global__ __launch_bounds__(NTH) void conv_c128_kernel(const C128Args a, const 
             for (int ks = 0; ks < 4; ++ks) wf[tap * 4 + ks] = *reinterpret_cast<const f16x8*>(stg + ((rho * 8 + ((2 * ks + lh) ^ (rho & 7))) << 4));
         }
     }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the copies are older than the weights: long landed
+    C128_STAMP(2)
     asm volatile("s_barrier" ::: "memory");  // strip, weights and parameters are in place
     C128_STAMP(3)
 
