@@ -664,7 +664,7 @@ int y5_launch_conv(const y5_conv_desc& d, hipStream_t s, const Y5ConvStats* st) 
 
 int y5_conv_variant_count() { return kNumIgemm + kNumHalo + kNumWs + kNumWs3 + y5_conv_lw_count() + y5_conv_lin_count() + y5_conv_p1x1_count() + y5_conv_s2c64_count() + y5_conv_s2c32_count(); }
 
-int y5_conv_cat2_variant_count() { return kNumCat2; }
+int y5_conv_cat2_variant_count() { return kNumCat2 + 1; }  // the tile configurations, then the persistent kernel (conv_p1x1.hip)
 int y5_conv_bf16_variant_count() { return kNumBf; }
 
 // d: the convolution with x = the half-resolution tensor (batch, ho/2, wo/2, cin), h = ho, w_in = wo the OUTPUT
@@ -687,10 +687,15 @@ int y5_launch_conv_cat2(const y5_conv_desc& d, const void* x2, int x2_ld, int ci
     Y5_REQUIRE(y5_aligned16(d.bias) && y5_aligned16(d.scale) && y5_aligned16(d.shift), "conv_cat2: per-channel vectors must be 16-byte aligned");
     Y5_REQUIRE(d.act == Y5_ACT_NONE || d.act == Y5_ACT_LEAKY, "conv_cat2: unknown activation %d", d.act);
     Y5_REQUIRE(d.act == Y5_ACT_NONE || (d.slope > 0.f && d.slope <= 1.f), "conv_cat2: LeakyReLU slope %g outside (0, 1]", (double)d.slope);
-    Y5_REQUIRE(d.variant >= 0 && d.variant <= kNumCat2, "conv_cat2: variant %d out of range 0..%d", d.variant, kNumCat2);
+    Y5_REQUIRE(d.variant >= 0 && d.variant <= kNumCat2 + 1, "conv_cat2: variant %d out of range 0..%d", d.variant, kNumCat2 + 1);
     const long long x_span = (((long long)d.batch * (d.ho / 2) * (d.wo / 2) - 1) * d.x_ld + d.cin) * 2;
     const long long x2_span = (((long long)d.batch * d.ho * d.wo - 1) * x2_ld + cin2) * 2;
     Y5_REQUIRE(x_span < 0x7fffffffLL && x2_span < 0x7fffffffLL && (long long)d.w_rows * d.kpad * 2 < 0x7fffffffLL, "conv_cat2: a tensor of 2 GiB or more");
+    if (d.variant == kNumCat2 + 1) {
+        int rc = Y5_OK;
+        if (y5_try_conv_p1x1_cat2(d, x2, x2_ld, cin2, s, &rc)) return rc;
+        return y5_fail(Y5_EINVAL, "conv_cat2: the persistent variant %d takes 128 + 128 input and 128 output channels, no residual", d.variant);
+    }
     ConvArgs a{};
     a.x = static_cast<const f16*>(d.x);
     a.x2 = static_cast<const f16*>(x2);

@@ -349,6 +349,143 @@ __global__ __launch_bounds__(NTH) void conv_p1x1_chain_kernel(const P1ChainArgs 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same kernel for a 1x1 convolution of the concatenation [nearest-2x-upsampled a | b] (nn.Upsample -> Concat -> the
+// cv1 | cv2 of the head's BottleneckCSP, models/yolov5s.yaml head rows 11-13 / 15-17) with neither tensor built: 128
+// channels from pixel (oy / 2, ox / 2) of the half-resolution a, 128 from pixel (oy, ox) of b.  A staged tile is two
+// planes of [pixel][128 channels] rows (16 slots each, slot s of pixel p at s ^ (p & 15)) - a 1 KiB copy then reads one
+// source through one descriptor - and K-steps 0-7 multiply from the first plane, 8-15 from the second.
+struct P1CatArgs {
+    P1Args f;          // x = a (half resolution), x_ld / x_bytes its pitch and span
+    const f16* x2;     // b
+    int x2_ld, x2_bytes;
+    int H, W;          // output (= b's) height and width
+    FastDiv div_hw, div_w;
+};
+
+template <int NCW, int NT>
+struct P1CatCfg {
+    static constexpr int KSH = 8, KS = 2 * KSH, CO = 32 * NCW, PXW = NWC / NCW;
+    static constexpr int TP = 32 * NT * PXW;
+    static constexpr int XROW = 16 * 16, PLANE = TP * XROW, X_BYTES = 2 * PLANE, PIECES = X_BYTES / 1024, MYP = PIECES / NWC;
+    static_assert(MYP * NWC * 1024 == X_BYTES && (PIECES / 2) % NWC == 0, "every wave copies the same number of whole pieces of each plane");
+    static constexpr int PRM0 = NBUF * X_BYTES, SMEM = PRM0 + 3 * CO * 4;
+    static_assert(SMEM <= 160 * 1024, "fits the CU's LDS");
+};
+
+template <int NCW, int NT, int F>
+__global__ __launch_bounds__(NTH) void conv_p1x1_cat_kernel(const P1CatArgs c) {
+    typedef P1CatCfg<NCW, NT> Cfg;
+    constexpr int MYP = Cfg::MYP, KS = Cfg::KS, HALF = Cfg::PIECES / 2;
+    const P1Args& a = c.f;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int t = threadIdx.x, lane = t & 63, lr = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int nwg = gridDim.x, g = xcd_remap(blockIdx.x, nwg);  // equal runs of pixels, as in conv_p1x1_kernel
+    const int run0 = (int)((long long)g * a.npix / nwg), run1 = (int)((long long)(g + 1) * a.npix / nwg);
+    const int first = 0, last = (run1 - run0 + Cfg::TP - 1) / Cfg::TP;
+
+    float* prm = reinterpret_cast<float*>(smem + Cfg::PRM0);
+    static_assert(Cfg::CO <= NTH, "one channel's parameters per thread");
+    float pv[3] = {0.f, 1.f, 0.f};
+    if (t < Cfg::CO) {
+        if (a.bias) pv[0] = a.bias[t];
+        if (a.scale) {
+            pv[1] = a.scale[t];
+            pv[2] = a.shift[t];
+        }
+    }
+    const int mt = wave % NCW, pg = wave / NCW;
+
+    // the copies: wave w issues pieces w, w + 8, ...; pieces below HALF fill the plane of a, the others the plane of b
+    const i32x4 ar = make_buf(a.x, a.x_bytes), br = make_buf(c.x2, c.x2_bytes);
+    int cpx[MYP], csl[MYP];  // per-lane constants: pixel within the tile, 16 x (source chunk of the lane's slot)
+#pragma unroll
+    for (int j = 0; j < MYP; ++j) {
+        const int d = wave + NWC * j, dd = d < HALF ? d : d - HALF;
+        const int slot = dd * 64 + lane, px = slot >> 4, sp = slot & 15;
+        cpx[j] = px;
+        csl[j] = (sp ^ (px & 15)) << 4;
+    }
+    const int Ha = c.H >> 1, Wa = c.W >> 1;
+    auto issue = [&](int tile, int buf) {
+        const int pix0 = run0 + tile * Cfg::TP, left = run1 - pix0;
+#pragma unroll
+        for (int j = 0; j < MYP; ++j) {
+            const int d = wave + NWC * j;  // wave-uniform: a piece reads one source
+            const unsigned P = (unsigned)(pix0 + cpx[j]);
+            unsigned off;
+            if (d < HALF) {
+                const unsigned b = fdiv(P, c.div_hw), rem = P - b * (unsigned)(c.H * c.W);
+                const unsigned oy = fdiv(rem, c.div_w), ox = rem - oy * (unsigned)c.W;
+                off = ((b * (unsigned)Ha + (oy >> 1)) * (unsigned)Wa + (ox >> 1)) * (unsigned)(a.x_ld * 2) + (unsigned)csl[j];
+            } else {
+                off = P * (unsigned)(c.x2_ld * 2) + (unsigned)csl[j];
+            }
+            dma16_buf(d < HALF ? ar : br, cpx[j] < left ? off : Y5_BUF_OOB, (unsigned)(buf * Cfg::X_BYTES + d * 1024));
+        }
+    };
+
+    int uoff[NT];  // byte offset within a plane of this lane's K-step-0 fragment per pixel group; K-step k of the plane: offset ^ (k << 5)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int px = (pg * NT + nt) * 32 + lr;
+        uoff[nt] = px * Cfg::XROW + ((lh ^ (px & 15)) << 4);
+    }
+    float negzero;
+    asm volatile("v_mov_b32 %0, 0x80000000" : "=v"(negzero));
+
+    if (first < last) issue(first, 0);  // before the weights are fetched: one round trip for parameters, weights and copies
+    f16x8 wf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) wf[ks] = *reinterpret_cast<const f16x8*>(a.w + (size_t)(mt * 32 + perm_row(lr)) * a.w_ld + ks * 16 + lh * 8);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // from here on the only loads in flight are the copies counted below
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(wf[ks]));
+    if (t < Cfg::CO) {
+        prm[t] = pv[0];
+        prm[Cfg::CO + t] = pv[1];
+        prm[2 * Cfg::CO + t] = pv[2];
+    }
+    if (first + 1 < last) issue(first + 1, 1);  // two tiles ahead, as in conv_p1x1_kernel
+    Prm16<F> q;
+    bool have_prm = false;
+    int buf = 0;
+    for (int tile = first; tile < last; ++tile) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave's pieces of this tile have landed; tile - 1 is read
+        if (tile + 2 < last) issue(tile + 2, buf == 0 ? NBUF - 1 : buf - 1);  // the buffer that held tile - 1
+        if (!have_prm) {
+            q.load(prm, Cfg::CO, mt * 32 + 16 * lh);
+            have_prm = true;
+        }
+        const unsigned char* X = smem + buf * Cfg::X_BYTES;
+        f16x8 lo[NT], hi[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x16 acc = zero16();
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], *reinterpret_cast<const f16x8*>(X + (ks / Cfg::KSH) * Cfg::PLANE + (uoff[nt] ^ ((ks % Cfg::KSH) << 5))), acc, 0, 0, 0);
+            finish<F>(acc, q, a.slope, negzero, lo[nt], hi[nt]);
+        }
+        if (tile + 2 < last)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MYP) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int pix0 = run0 + tile * Cfg::TP;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int pix = pix0 + (pg * NT + nt) * 32 + lr;
+            if (pix < run1) {
+                f16* yp = a.y + (size_t)pix * a.y_ld + mt * 32 + 16 * lh;
+                *reinterpret_cast<f16x8*>(yp) = lo[nt];
+                *reinterpret_cast<f16x8*>(yp + 8) = hi[nt];
+            }
+        }
+        buf = buf == NBUF - 1 ? 0 : buf + 1;
+    }
+}
+
 int cu_count() {  // compute units of the current device (one persistent workgroup each)
     static std::atomic<int> cached[64];
     const int dev = y5_current_device();
@@ -395,6 +532,22 @@ int launch_chain(P1ChainArgs& c, hipStream_t s) {
     const int cus = cu_count();
     hipLaunchKernelGGL((conv_p1x1_chain_kernel<KS, NCW, KS2, NCW2>), dim3((unsigned)(c.f.ntiles < cus ? c.f.ntiles : cus)), dim3(NTH), (size_t)Cfg::SMEM, s, c);
     Y5_LAUNCH_CHECK("conv_p1x1_chain_kernel");
+    return Y5_OK;
+}
+
+template <int NCW, int NT, int F>
+int launch_cat_f(P1CatArgs& c, hipStream_t s) {
+    typedef P1CatCfg<NCW, NT> Cfg;
+    static std::atomic<unsigned long long> attr_set{0};
+    const unsigned long long bit = 1ull << y5_current_device();
+    if (!(attr_set.load() & bit)) {
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p1x1_cat_kernel<NCW, NT, F>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+        attr_set.fetch_or(bit);
+    }
+    c.f.ntiles = (c.f.npix + Cfg::TP - 1) / Cfg::TP;
+    const int cus = cu_count();
+    hipLaunchKernelGGL((conv_p1x1_cat_kernel<NCW, NT, F>), dim3((unsigned)(c.f.ntiles < cus ? c.f.ntiles : cus)), dim3(NTH), (size_t)Cfg::SMEM, s, c);
+    Y5_LAUNCH_CHECK("conv_p1x1_cat_kernel");
     return Y5_OK;
 }
 
@@ -459,5 +612,33 @@ int y5_try_conv_p1x1_chain(const y5_conv_desc& f, const y5_conv_desc& g, int kee
     c.w2_ld = g.kpad; c.y2_ld = g.y_ld;
     c.slope2 = g.act == Y5_ACT_LEAKY ? g.slope : 1.f;
     *rc = shape == 1 ? launch_chain<16, 8, 8, 4>(c, s) : launch_chain<8, 4, 4, 2>(c, s);
+    return 1;
+}
+
+// 1x1 stride-1 convolution of [nearest-2x-upsampled x | x2] as the persistent kernel: compiled for 128 + 128 input and 128
+// output channels without a residual.  Returns 0 when the convolution is outside that (then *rc is untouched), 1 after a
+// launch attempt with its status in *rc.  d, x2, x2_ld and cin2 were validated by y5_launch_conv_cat2.
+int y5_try_conv_p1x1_cat2(const y5_conv_desc& d, const void* x2, int x2_ld, int cin2, hipStream_t s, int* rc) {
+    if (d.cin != 128 || cin2 != 128 || d.cout != 128 || d.res) return 0;
+    if (d.w_rows < d.cout || d.kpad < d.cin + cin2) return 0;
+    const long long npix = (long long)d.batch * d.ho * d.wo;
+    const long long ab = (((long long)d.batch * (d.ho / 2) * (d.wo / 2) - 1) * d.x_ld + d.cin) * 2, bb = ((npix - 1) * x2_ld + cin2) * 2;
+    if (npix <= 0 || npix >= 0x7fffffffLL || ab >= 0x7fffffffLL || bb >= 0x7fffffffLL) return 0;
+    P1CatArgs c{};
+    P1Args& a = c.f;
+    a.x = static_cast<const f16*>(d.x);
+    a.y = static_cast<f16*>(d.y);
+    a.w = static_cast<const f16*>(d.w);
+    a.bias = d.bias; a.scale = d.scale; a.shift = d.shift;
+    a.w_ld = d.kpad; a.x_ld = d.x_ld; a.y_ld = d.y_ld; a.x_bytes = (int)ab;
+    a.npix = (int)npix;
+    a.slope = d.act == Y5_ACT_LEAKY ? d.slope : 1.f;
+    c.x2 = static_cast<const f16*>(x2);
+    c.x2_ld = x2_ld; c.x2_bytes = (int)bb;
+    c.H = d.ho; c.W = d.wo;
+    c.div_hw = make_fastdiv((unsigned)(d.ho * d.wo));
+    c.div_w = make_fastdiv((unsigned)d.wo);
+    const int f = (d.bias ? 1 : 0) | (d.scale ? 2 : 0);
+    *rc = f == 0 ? launch_cat_f<4, 1, 0>(c, s) : f == 1 ? launch_cat_f<4, 1, 1>(c, s) : f == 2 ? launch_cat_f<4, 1, 2>(c, s) : launch_cat_f<4, 1, 3>(c, s);
     return 1;
 }

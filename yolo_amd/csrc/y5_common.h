@@ -130,6 +130,7 @@ int y5_conv_s2c64_count();
 int y5_try_conv_p1x1(const y5_conv_desc& d, hipStream_t s, int which, int* rc);
 int y5_conv_p1x1_count();
 int y5_try_conv_p1x1_chain(const y5_conv_desc& f, const y5_conv_desc& g, int keep_first, hipStream_t s, int* rc);
+int y5_try_conv_p1x1_cat2(const y5_conv_desc& d, const void* x2, int x2_ld, int cin2, hipStream_t s, int* rc);
 int y5_launch_detect(const y5_conv_desc& c, const y5_decode_desc& d, int variant, hipStream_t s);
 int y5_detect_variant_count();
 int y5_try_detect_persistent(const y5_conv_desc& c, const y5_decode_desc& d, hipStream_t s, int* rc);
