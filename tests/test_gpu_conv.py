@@ -659,7 +659,8 @@ def test_stem_conv_from_the_nchw_image(dev, shape):
 @pytest.mark.parametrize('shape', [(2, 64, 64, 40, 24, 16), (1, 128, 72, 255, 40, 40), (3, 256, 256, 256, 8, 12), (2, 64, 8, 16, 6, 10),
                                    (1, 192, 104, 136, 20, 18),
                                    # 128 + 128 -> 128: also the persistent kernel (whole and ragged pixel runs, fewer pixels than one tile per CU)
-                                   (4, 128, 128, 128, 40, 40), (2, 128, 128, 128, 12, 22), (1, 128, 128, 128, 6, 10)], ids=lambda s: 'x'.join(map(str, s)))
+                                   (4, 128, 128, 128, 40, 40), (2, 128, 128, 128, 12, 22), (1, 128, 128, 128, 6, 10),
+                                   (3, 256, 256, 256, 20, 20), (2, 256, 256, 256, 10, 14)], ids=lambda s: 'x'.join(map(str, s)))
 def test_conv_cat2_equals_upsample_concat_conv(dev, shape):
     """y5_conv_cat2_f16 (1x1 conv of [nearest-2x-upsampled a | b], neither tensor built) against upsampling, concatenating
     and y5_conv_f16, for every compiled tile shape; with residual, bias, folded BatchNorm and LeakyReLU."""
@@ -698,8 +699,8 @@ def test_conv_cat2_equals_upsample_concat_conv(dev, shape):
             taken += 1
             close(y.permute(0, 3, 1, 2), ref.permute(0, 3, 1, 2))
         assert taken >= 5
-        if (Ca, Cb, Co) == (128, 128, 128) and not use_res:
-            assert rc == 0, 'the persistent kernel (last variant) must take 128 + 128 -> 128 without a residual'
+        if (Ca, Cb, Co) in ((128, 128, 128), (256, 256, 256)) and not use_res:
+            assert rc == 0, 'the persistent kernel (last variant) must take 128 + 128 -> 128 and 256 + 256 -> 256 without a residual'
         else:
             assert rc == _lib.EINVAL
     # rejected: odd output size, a first source that is not a multiple of 64 channels wide, a 3x3 kernel

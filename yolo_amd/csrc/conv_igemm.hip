@@ -694,7 +694,7 @@ int y5_launch_conv_cat2(const y5_conv_desc& d, const void* x2, int x2_ld, int ci
     if (d.variant == kNumCat2 + 1) {
         int rc = Y5_OK;
         if (y5_try_conv_p1x1_cat2(d, x2, x2_ld, cin2, s, &rc)) return rc;
-        return y5_fail(Y5_EINVAL, "conv_cat2: the persistent variant %d takes 128 + 128 input and 128 output channels, no residual", d.variant);
+        return y5_fail(Y5_EINVAL, "conv_cat2: the persistent variant %d takes 128 + 128 -> 128 or 256 + 256 -> 256 channels, no residual", d.variant);
     }
     ConvArgs a{};
     a.x = static_cast<const f16*>(d.x);

@@ -352,9 +352,11 @@ __global__ __launch_bounds__(NTH) void conv_p1x1_chain_kernel(const P1ChainArgs 
 // ---------------------------------------------------------------------------------------------------------------------
 // The same kernel for a 1x1 convolution of the concatenation [nearest-2x-upsampled a | b] (nn.Upsample -> Concat -> the
 // cv1 | cv2 of the head's BottleneckCSP, models/yolov5s.yaml head rows 11-13 / 15-17) with neither tensor built: 128
-// channels from pixel (oy / 2, ox / 2) of the half-resolution a, 128 from pixel (oy, ox) of b.  A staged tile is two
-// planes of [pixel][128 channels] rows (16 slots each, slot s of pixel p at s ^ (p & 15)) - a 1 KiB copy then reads one
-// source through one descriptor - and K-steps 0-7 multiply from the first plane, 8-15 from the second.
+// half of the channels from pixel (oy / 2, ox / 2) of the half-resolution a, half from pixel (oy, ox) of b.  A staged tile
+// is two planes of [pixel][channel] rows (slot s of pixel p at s ^ (p & 15)) - a 1 KiB copy then reads one
+// source through one descriptor - and the first half of the K-steps multiplies from the first plane, the second half from
+// the second.  Compiled for 128 + 128 -> 128 channels (80 x 80 in yolov5s) and 256 + 256 -> 256 (40 x 40: 128 weight
+// registers per wave, tiles of 32 pixels).
 struct P1CatArgs {
     P1Args f;          // x = a (half resolution), x_ld / x_bytes its pitch and span
     const f16* x2;     // b
@@ -363,19 +365,20 @@ struct P1CatArgs {
     FastDiv div_hw, div_w;
 };
 
-template <int NCW, int NT>
+template <int KSH, int NCW, int NT>  // 16 KSH channels per source
 struct P1CatCfg {
-    static constexpr int KSH = 8, KS = 2 * KSH, CO = 32 * NCW, PXW = NWC / NCW;
+    static constexpr int KS = 2 * KSH, CO = 32 * NCW, PXW = NWC / NCW;
     static constexpr int TP = 32 * NT * PXW;
-    static constexpr int XROW = 16 * 16, PLANE = TP * XROW, X_BYTES = 2 * PLANE, PIECES = X_BYTES / 1024, MYP = PIECES / NWC;
+    static constexpr int SLOTS = 2 * KSH, XROW = SLOTS * 16, PLANE = TP * XROW, X_BYTES = 2 * PLANE, PIECES = X_BYTES / 1024, MYP = PIECES / NWC;
+    static_assert(SLOTS >= 16 && (SLOTS & (SLOTS - 1)) == 0, "the swizzle needs rows of 16 slots or more");
     static_assert(MYP * NWC * 1024 == X_BYTES && (PIECES / 2) % NWC == 0, "every wave copies the same number of whole pieces of each plane");
     static constexpr int PRM0 = NBUF * X_BYTES, SMEM = PRM0 + 3 * CO * 4;
     static_assert(SMEM <= 160 * 1024, "fits the CU's LDS");
 };
 
-template <int NCW, int NT, int F>
+template <int KSH, int NCW, int NT, int F>
 __global__ __launch_bounds__(NTH) void conv_p1x1_cat_kernel(const P1CatArgs c) {
-    typedef P1CatCfg<NCW, NT> Cfg;
+    typedef P1CatCfg<KSH, NCW, NT> Cfg;
     constexpr int MYP = Cfg::MYP, KS = Cfg::KS, HALF = Cfg::PIECES / 2;
     const P1Args& a = c.f;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(NTH) void conv_p1x1_cat_kernel(const P1CatArgs c) {
 #pragma unroll
     for (int j = 0; j < MYP; ++j) {
         const int d = wave + NWC * j, dd = d < HALF ? d : d - HALF;
-        const int slot = dd * 64 + lane, px = slot >> 4, sp = slot & 15;
+        const int slot = dd * 64 + lane, px = slot / Cfg::SLOTS, sp = slot % Cfg::SLOTS;
         cpx[j] = px;
         csl[j] = (sp ^ (px & 15)) << 4;
     }
@@ -465,7 +468,7 @@ __global__ __launch_bounds__(NTH) void conv_p1x1_cat_kernel(const P1CatArgs c) {
             f32x16 acc = zero16();
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], *reinterpret_cast<const f16x8*>(X + (ks / Cfg::KSH) * Cfg::PLANE + (uoff[nt] ^ ((ks % Cfg::KSH) << 5))), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], *reinterpret_cast<const f16x8*>(X + (ks / KSH) * Cfg::PLANE + (uoff[nt] ^ ((ks % KSH) << 5))), acc, 0, 0, 0);
             finish<F>(acc, q, a.slope, negzero, lo[nt], hi[nt]);
         }
         if (tile + 2 < last)
@@ -535,18 +538,18 @@ int launch_chain(P1ChainArgs& c, hipStream_t s) {
     return Y5_OK;
 }
 
-template <int NCW, int NT, int F>
+template <int KSH, int NCW, int NT, int F>
 int launch_cat_f(P1CatArgs& c, hipStream_t s) {
-    typedef P1CatCfg<NCW, NT> Cfg;
+    typedef P1CatCfg<KSH, NCW, NT> Cfg;
     static std::atomic<unsigned long long> attr_set{0};
     const unsigned long long bit = 1ull << y5_current_device();
     if (!(attr_set.load() & bit)) {
-        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p1x1_cat_kernel<NCW, NT, F>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p1x1_cat_kernel<KSH, NCW, NT, F>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
         attr_set.fetch_or(bit);
     }
     c.f.ntiles = (c.f.npix + Cfg::TP - 1) / Cfg::TP;
     const int cus = cu_count();
-    hipLaunchKernelGGL((conv_p1x1_cat_kernel<NCW, NT, F>), dim3((unsigned)(c.f.ntiles < cus ? c.f.ntiles : cus)), dim3(NTH), (size_t)Cfg::SMEM, s, c);
+    hipLaunchKernelGGL((conv_p1x1_cat_kernel<KSH, NCW, NT, F>), dim3((unsigned)(c.f.ntiles < cus ? c.f.ntiles : cus)), dim3(NTH), (size_t)Cfg::SMEM, s, c);
     Y5_LAUNCH_CHECK("conv_p1x1_cat_kernel");
     return Y5_OK;
 }
@@ -616,10 +619,11 @@ int y5_try_conv_p1x1_chain(const y5_conv_desc& f, const y5_conv_desc& g, int kee
 }
 
 // 1x1 stride-1 convolution of [nearest-2x-upsampled x | x2] as the persistent kernel: compiled for 128 + 128 input and 128
-// output channels without a residual.  Returns 0 when the convolution is outside that (then *rc is untouched), 1 after a
+// output channels and for 256 + 256 -> 256, without a residual.  Returns 0 when the convolution is outside that (then *rc is untouched), 1 after a
 // launch attempt with its status in *rc.  d, x2, x2_ld and cin2 were validated by y5_launch_conv_cat2.
 int y5_try_conv_p1x1_cat2(const y5_conv_desc& d, const void* x2, int x2_ld, int cin2, hipStream_t s, int* rc) {
-    if (d.cin != 128 || cin2 != 128 || d.cout != 128 || d.res) return 0;
+    const bool small = d.cin == 128 && cin2 == 128 && d.cout == 128, big = d.cin == 256 && cin2 == 256 && d.cout == 256;
+    if ((!small && !big) || d.res) return 0;
     if (d.w_rows < d.cout || d.kpad < d.cin + cin2) return 0;
     const long long npix = (long long)d.batch * d.ho * d.wo;
     const long long ab = (((long long)d.batch * (d.ho / 2) * (d.wo / 2) - 1) * d.x_ld + d.cin) * 2, bb = ((npix - 1) * x2_ld + cin2) * 2;
@@ -639,6 +643,7 @@ int y5_try_conv_p1x1_cat2(const y5_conv_desc& d, const void* x2, int x2_ld, int 
     c.div_hw = make_fastdiv((unsigned)(d.ho * d.wo));
     c.div_w = make_fastdiv((unsigned)d.wo);
     const int f = (d.bias ? 1 : 0) | (d.scale ? 2 : 0);
-    *rc = f == 0 ? launch_cat_f<4, 1, 0>(c, s) : f == 1 ? launch_cat_f<4, 1, 1>(c, s) : f == 2 ? launch_cat_f<4, 1, 2>(c, s) : launch_cat_f<4, 1, 3>(c, s);
+    if (small) *rc = f == 0 ? launch_cat_f<8, 4, 1, 0>(c, s) : f == 1 ? launch_cat_f<8, 4, 1, 1>(c, s) : f == 2 ? launch_cat_f<8, 4, 1, 2>(c, s) : launch_cat_f<8, 4, 1, 3>(c, s);
+    else *rc = f == 0 ? launch_cat_f<16, 8, 1, 0>(c, s) : f == 1 ? launch_cat_f<16, 8, 1, 1>(c, s) : f == 2 ? launch_cat_f<16, 8, 1, 2>(c, s) : launch_cat_f<16, 8, 1, 3>(c, s);
     return 1;
 }
