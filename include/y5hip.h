@@ -151,7 +151,9 @@ int y5_csp_f16(const y5_csp_desc* d, y5_stream_t stream);
  * Descriptor as for y5_conv_f16 with ksize = 1, stride = 1, pad = 0 and these meanings: h = ho, w_in = wo = the OUTPUT
  * size (even); x = the half-resolution tensor (batch, ho/2, wo/2, cin) with pitch x_ld, cin a multiple of 64; x2 =
  * (batch, ho, wo, cin2) with pitch x2_ld.  A weight row holds cin + cin2 values, x's channels first (kpad >= cin + cin2).
- * Output pixel (oy, ox) reads x at (oy/2, ox/2) and x2 at (oy, ox).  variant: 0 or 1..y5_conv_cat2_num_variants().
+ * Output pixel (oy, ox) reads x at (oy/2, ox/2) and x2 at (oy, ox).  variant: 0 or 1..y5_conv_cat2_num_variants(); the
+ * last one is a persistent kernel with the weights in registers, compiled for 128 + 128 -> 128 and 256 + 256 -> 256
+ * channels without a residual (Y5_EINVAL for other shapes).
  * Same values as upsampling, concatenating and calling y5_conv_f16. */
 int y5_conv_cat2_f16(const y5_conv_desc* d, const void* x2, int x2_ld, int cin2, y5_stream_t stream);
 int y5_conv_cat2_num_variants(void);
