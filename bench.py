@@ -266,7 +266,7 @@ def main():
             with open(tpath) as f:
                 traffic = json.load(f).get('conv_total')  # rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of the same launches
         top = sorted(conv, key=lambda a: -a['ms'])[:6]
-        roofline = {'kernel': 'convolution kernels (stem2 / csp1 / conv_c64 / conv_s2c64 / conv_p1x1 / conv_igemm / conv_lw / conv_lin3 / conv_ws1x1 / conv3x3_ws / detect_p): all %d launches of one forward'
+        roofline = {'kernel': 'convolution kernels (stem2 / csp1 / conv_c64 / conv_c128 / conv_s2c64 / conv_p1x1 / conv_p1x1_cat / conv_igemm / conv_lw / conv_lin3 / conv_ws1x1 / conv3x3_ws / detect_p): all %d launches of one forward'
                               % len(conv),
                     'bound': 'hbm' if hbm_bound else 'mfma',
                     'achieved': round(gbs if hbm_bound else tflops, 2), 'peak': PEAK_HBM_GBS if hbm_bound else PEAK_MFMA_TFLOPS,

@@ -28,7 +28,7 @@ def family(name):
     for key, fam in (('csp1_kernel', 'conv_csp'), ('detect_p_kernel', 'conv_detect'), ('stem2_kernel', 'conv_stem2')):
         if key in name:
             return fam
-    for key in ('focus_conv', 'conv_lw', 'conv_lin3', 'conv_c64', 'conv_p1x1', 'conv_s2c64', 'conv_s2c32', 'conv_igemm', 'conv_halo', 'conv_ws1x1', 'conv3x3_ws', 'detect_decode', 'nms_', 'maxpool', 'upsample', 'copy_channels'):
+    for key in ('focus_conv', 'conv_lw', 'conv_lin3', 'conv_c64', 'conv_c128', 'conv_p1x1', 'conv_s2c64', 'conv_s2c32', 'conv_igemm', 'conv_halo', 'conv_ws1x1', 'conv3x3_ws', 'detect_decode', 'nms_', 'maxpool', 'upsample', 'copy_channels'):
         if key in name:
             return key
     return 'other'
