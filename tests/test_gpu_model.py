@@ -128,6 +128,12 @@ def test_interleaved_bgr_frames_run_like_the_loaders_tensor(dev, cfg):
     with engine.disabled():
         zt, _ = model(x)
     agree(z1, zt, 0.80)
+    # a view that lost from_hwc's marking (slicing, .to(device), a collate function) is rejected, not read as RGB
+    for lost in (x[:1], x.cpu().to(dev)):
+        with pytest.raises(TypeError, match='from_hwc'):
+            model(lost)
+    with pytest.raises(TypeError, match='augment'):
+        model(x, augment=True)
     zc, _ = model.float().cpu()(preprocess.from_hwc(torch.from_numpy(frames), bgr=True))   # off the GPU: flip + convert + divide
     agree(z1, zc, 0.0, rel=3e-2)
 
@@ -274,3 +280,92 @@ def test_concat_with_a_3x3_reader_is_built(dev):
     with engine.disabled():
         zt, _ = model(x)
     agree(z, zt, 0.80)
+
+
+KNOBS = ['Y5_CHAIN_LINK', 'Y5_CHAIN_HEAD', 'Y5_CHAIN_FUSE', 'Y5_CSP_FUSE', 'Y5_CAT2_FUSE', 'Y5_DETECT_FUSE', 'Y5_STEM2_FUSE',
+         'Y5_FOCUS_FUSE', 'Y5_DECODE_FUSE', 'Y5_AUTOTUNE']
+
+
+@pytest.mark.parametrize('knob', KNOBS)
+def test_every_fusion_knob_off_still_matches_the_oracle(dev, monkeypatch, knob):
+    """Each environment switch that turns one fusion of the plan builder off must leave a correct plan: BottleneckCSPs with
+    three Bottlenecks (yolov5s layers 4 and 6) exercise the chained kernels with and without the links between them."""
+    model = util.build_model('yolov5s')
+    util.randomize_bn(model, 11)
+    model = model.eval().half().to(dev)
+    x = torch.rand(2, 3, 128, 160, generator=torch.Generator().manual_seed(5)).half()
+    cfgd = yaml.safe_load(open(os.path.join(util.CFG_DIR, 'yolov5s.yaml')))
+    sd = {k: v.float().cpu() for k, v in model.state_dict().items()}
+    zr, xr = y5ref.forward(cfgd, sd, x.float(), precision='half', strides=model.stride)
+    monkeypatch.setenv(knob, '0')
+    plan = engine.Plan(model, x.to(dev))
+    try:
+        z, xs = plan.run(x.to(dev))
+        torch.cuda.synchronize()
+    finally:
+        plan.close()
+    agree(z, zr, 0.90)
+    for a, b in zip(xs, xr):
+        agree(a, b, 0.60)
+
+
+def test_plan_is_rebuilt_after_model_changes_and_not_otherwise(dev):
+    """fuse(), a dtype round trip (filter_pruning/fp_test.py:128,327), load_state_dict and a pruning-style Parameter
+    assignment each give a new plan whose output follows the change; repeated forwards walk the model once."""
+    model = util.build_model('yolov5s')
+    util.randomize_bn(model, 7)
+    model = model.eval().half().to(dev)
+    x = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(2)).half().to(dev)
+    z0, _ = model(x)
+    eng = engine.engine_of(model)
+    plan0 = next(iter(eng.plans.values()))
+    walks = eng.walks
+    for _ in range(3):
+        z1, _ = model(x)
+    assert eng.walks == walks and next(iter(eng.plans.values())) is plan0 and torch.equal(z0, z1)
+
+    def torch_walk():
+        with engine.disabled():
+            return model(x)[0]
+    with torch.no_grad():
+        model.model[0].conv.conv.weight.mul_(1.5)          # in place: version counter
+    z2, _ = model(x)
+    assert next(iter(eng.plans.values())) is not plan0 and not torch.equal(z2, z0)
+    agree(z2, torch_walk(), 0.80)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    sd['model.1.conv.weight'] = sd['model.1.conv.weight'] * 0.5
+    model.load_state_dict(sd)
+    z3, _ = model(x)
+    assert not torch.equal(z3, z2)
+    agree(z3, torch_walk(), 0.80)
+    model.float().half()                                    # new storage for every tensor
+    z4, _ = model(x)
+    assert torch.equal(z4, z3)
+    util.quiet(model.fuse)
+    z5, _ = model(x)
+    agree(z5, torch_walk(), 0.80)
+    conv = model.model[-1].m[0]
+    with torch.no_grad():
+        conv.weight = torch.nn.Parameter(conv.weight * 2.0)  # pruning assigns new Parameters
+    z6, _ = model(x)
+    assert not torch.equal(z6, z5)
+    agree(z6, torch_walk(), 0.80)
+    assert calls(model) == 9
+
+
+def test_side_stream_nms_with_overflow_check_equals_the_serial_call(dev):
+    """nms_padded(stream=side) with the default check_overflow reads the candidate totals on `side`: results bit-equal to
+    the serial call, also when the first capacity is too small and the call repeats itself with a larger one."""
+    from yolo_amd import nms as hip_nms
+    g = torch.Generator().manual_seed(3)
+    pred = torch.rand(3, 4096, 85, generator=g)
+    pred[..., :4] *= 300.0
+    pred = pred.half().to(dev)
+    side = torch.cuda.Stream(dev)
+    serial = hip_nms.nms_padded(pred, 0.3, 0.6, return_index=True)
+    for cap in (None, 1000):
+        got = hip_nms.nms_padded(pred, 0.3, 0.6, return_index=True, stream=side, max_candidates=cap)
+        side.synchronize()
+        assert int(got[3].max()) > 1000
+        for a, b in zip(got, serial):
+            assert torch.equal(a, b)

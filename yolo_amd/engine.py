@@ -22,6 +22,7 @@ import weakref
 
 import torch
 import torch.nn as nn
+import torch.nn.modules.module as _tm
 
 from yolo_amd import _lib
 from yolo_amd.utils.torch_utils import bn_affine
@@ -70,24 +71,64 @@ def _cache_key(key):
     return json.dumps(key)
 
 
+_REPLAYED = set()  # keys whose choice came from a file and has not been launched by this process yet
+
+
+def _fingerprint():
+    """What a variant id means depends on the library build (ids are positions in its kernel tables) and on the device:
+    a cache written under another build or architecture is ignored."""
+    import hashlib
+    lib = _lib.lib()
+    h = hashlib.sha1()
+    with open(_lib.LIB_PATH, 'rb') as f:
+        for block in iter(lambda: f.read(1 << 20), b''):
+            h.update(block)
+    arch = C.create_string_buffer(64)
+    if lib.y5_device_arch(arch, 64) != 0:
+        arch.value = b'unknown'
+    return {'library': h.hexdigest(), 'arch': arch.value.decode(), 'version': lib.y5_version(),
+            'variants': [lib.y5_conv_num_variants(), lib.y5_conv_num_variants_bf16(), lib.y5_conv_chain_num_variants(),
+                         lib.y5_conv_cat2_num_variants(), lib.y5_detect_num_variants()]}
+
+
 def load_tune_cache(path):
-    """Read variant choices written by save_tune_cache: later plans of those shapes take them without timing anything."""
+    """Read variant choices written by save_tune_cache: later plans of those shapes take them without timing anything
+    (each is launched once before it is recorded; one the library rejects is timed afresh).  Returns the number of
+    choices taken: 0 when the file was written under another library build or device architecture."""
     with open(path) as f:
         data = json.load(f)
+    if data.pop('__fingerprint__', None) != _fingerprint():
+        return 0
     for k, (variant, ms) in data.items():
         key = tuple(json.loads(k))
         _TUNED[key], _TUNED_MS[key] = int(variant), float(ms)
+        _REPLAYED.add(key)
     return len(data)
 
 
 def save_tune_cache(path):
-    """Write every variant choice of this process (shape key -> [variant, ms]) as JSON."""
+    """Write every variant choice of this process (shape key -> [variant, ms]) as JSON, with the library fingerprint."""
     data = {_cache_key(list(k)): [v, _TUNED_MS.get(k, 0.0)] for k, v in _TUNED.items()}
+    data['__fingerprint__'] = _fingerprint()
     tmp = '%s.%d.tmp' % (path, os.getpid())
     with open(tmp, 'w') as f:
         json.dump(data, f, indent=0, sort_keys=True)
     os.replace(tmp, path)
-    return len(data)
+    return len(data) - 1
+
+
+def _replay_ok(key, launch):
+    """True when `key` has a usable choice.  A choice read from a file is launched once first (launch(variant) -> status);
+    if the library rejects it, it is dropped so that the caller times the shape afresh."""
+    if key not in _TUNED:
+        return False
+    if key in _REPLAYED:
+        _REPLAYED.discard(key)
+        if launch(_TUNED[key]) != 0:
+            del _TUNED[key]
+            _TUNED_MS.pop(key, None)
+            return False
+    return True
 
 
 def _tune_cache_init():
@@ -99,8 +140,9 @@ def _tune_cache_init():
     if os.path.exists(path):
         try:
             load_tune_cache(path)
-        except (ValueError, OSError):
-            pass
+        except (ValueError, OSError, _lib.Y5Error) as e:
+            import warnings
+            warnings.warn('Y5_TUNE_CACHE %s ignored: %s' % (path, e))
     import atexit
     atexit.register(lambda: _TUNED and save_tune_cache(path))
 
@@ -128,9 +170,23 @@ def _supported_types():
             yolo.Detect, nn.Upsample, nn.Sequential)
 
 
+_REG_EPOCH = [0]  # bumped whenever a parameter, buffer or sub-module is assigned to ANY module of the process
+
+
+def _registered(*_):
+    _REG_EPOCH[0] += 1
+
+
+# nn.Module.__setattr__ / register_* run these for every assignment of a Parameter, a buffer or a sub-module: pruning
+# (filter_pruning/torch_pruning/prune/structured.py:50-60 assigns new Parameters), Model.fuse (models/yolo.py:155-163
+# replaces m.conv and clears m.bn) and model surgery in general are seen without walking the model on every forward.
+_tm.register_module_parameter_registration_hook(_registered)
+_tm.register_module_buffer_registration_hook(_registered)
+_tm.register_module_module_registration_hook(_registered)
+
+
 def _has_hooks(model):
-    import torch.nn.modules.module as tm
-    if tm._global_forward_hooks or tm._global_forward_pre_hooks:
+    if _tm._global_forward_hooks or _tm._global_forward_pre_hooks:
         return True
     for m in model.modules():
         if m._forward_hooks or m._forward_pre_hooks:
@@ -140,40 +196,64 @@ def _has_hooks(model):
 
 def input_layout(x):
     """How the image bytes of a 4-d (batch, channel, height, width) input lie in memory: _lib.IN_U8_HWC(_BGR) for a uint8
-    tensor that is a permuted view of a (batch, height, width, 3) array - torch's channels_last - optionally marked as
-    BGR by yolo_amd.preprocess.from_hwc; 0 for everything else (read as, or copied to, contiguous NCHW)."""
+    tensor that is a permuted view of a (batch, height, width, 3) array - torch's channels_last - as
+    yolo_amd.preprocess.from_hwc returns it; 0 for everything else (read as, or copied to, contiguous NCHW).
+    An interleaved uint8 view WITHOUT from_hwc's marking is rejected: slicing, .to(device), pin_memory or a collate
+    function return plain tensors, and guessing the channel order of those would silently swap red and blue."""
     if (x.dtype is torch.uint8 and x.dim() == 4 and x.shape[1] == 3 and not x.is_contiguous()
             and x.is_contiguous(memory_format=torch.channels_last)):
-        return _lib.IN_U8_HWC_BGR if getattr(x, 'y5_bgr', False) else _lib.IN_U8_HWC
+        bgr = getattr(x, 'y5_bgr', None)
+        if bgr is None:
+            raise TypeError('an interleaved (height, width, 3) uint8 batch must be passed through yolo_amd.preprocess.from_hwc '
+                            'right before the model call: this view does not say whether its channels are BGR or RGB '
+                            '(tensor operations such as slicing or .to(device) drop that marking)')
+        return _lib.IN_U8_HWC_BGR if bgr else _lib.IN_U8_HWC
     return 0
 
 
-def eligible(model, x):
-    """True when this forward may run on the HIP engine: inference mode on a GPU in fp16 or bf16, no autograd,
-    no module hooks (the pruning / FLOP-counting tools attach hooks and need the torch modules to run),
-    Detect.export off, 4-d input whose height and width are multiples of the largest stride."""
+def _plan_if_eligible(model, x):
+    """The launch plan that serves this forward, or None when it has to run on the torch modules: inference mode on a
+    GPU in fp16 or bf16, no autograd, no module hooks (the pruning / FLOP-counting tools attach hooks and need the torch
+    modules to run), Detect.export off, 4-d input whose height and width are multiples of the largest stride, every
+    top-level module lowered.  In the steady state (same model, same input shape) this costs one pass over the cached
+    tensor list (version counters and addresses) and one over the cached hook tables: no module walk."""
     if _DISABLED[0] or model.training or torch.is_grad_enabled():
-        return False
+        return None
     if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4):
-        return False
+        return None
+    eng = _engine_of(model)
+    st = eng.state()
     if x.dtype is torch.uint8:
         # the data loader's tensor (utils/datasets.py:140-141): the engine applies img.half() / 255.0 (test.py:152-154)
         # itself, inside the first kernel where it can; only meaningful for a half-precision model
-        if next(model.parameters()).dtype is not torch.float16:
-            return False
-    elif x.dtype not in (torch.float16, torch.bfloat16) or next(model.parameters()).dtype is not x.dtype:
-        return False
-    from yolo_amd.models.yolo import Detect
-    head = model.model[-1]
-    if not isinstance(head, Detect) or head.export or head.training:
-        return False
-    smax = int(max(head.stride)) if head.stride is not None else 32
-    if x.shape[2] % smax or x.shape[3] % smax:
-        return False
-    if _has_hooks(model):
-        return False
-    eng = _engine_of(model)
-    return eng.supported(x)
+        if st.dtype is not torch.float16:
+            return None
+    elif x.dtype not in (torch.float16, torch.bfloat16) or st.dtype is not x.dtype:
+        return None
+    head = st.head
+    if head is None or head.export or head.training:
+        return None
+    if x.shape[2] % st.smax or x.shape[3] % st.smax:
+        return None
+    if _tm._global_forward_hooks or _tm._global_forward_pre_hooks or any(st.hook_tables):
+        return None
+    if not st.types_ok:
+        return None
+    return eng._plan(x, st)
+
+
+def eligible(model, x):
+    """True when this forward may run on the HIP engine (see _plan_if_eligible)."""
+    return _plan_if_eligible(model, x) is not None
+
+
+def try_run(model, x):
+    """(z, [x_i]) from the HIP engine, or None when this forward is not eligible: ONE eligibility check and plan lookup
+    per forward."""
+    plan = _plan_if_eligible(model, x)
+    if plan is None:
+        return None
+    return _ENGINES[model]._run(plan, x)
 
 
 def run(model, x):
@@ -421,14 +501,14 @@ class Plan:
             return 0
         a, b = cat.a, cat.b
         key = ('cat2', d.batch, d.ho, d.wo, a.c_pad, a.ld, b.c_pad, b.ld, d.cout, d.y_ld, bool(d.res), bool(d.bias), bool(d.scale))
-        if key not in _TUNED:
+        stream = _lib.current_stream()
+
+        def launch(v):
+            d.variant = v
+            return self.lib.y5_conv_cat2_f16(C.byref(d), b.ptr, b.ld, b.c_pad, stream)
+        if not _replay_ok(key, launch):
             a.buf.uniform_(-1.0, 1.0)
             b.buf.uniform_(-1.0, 1.0)
-            stream = _lib.current_stream()
-
-            def launch(v):
-                d.variant = v
-                return self.lib.y5_conv_cat2_f16(C.byref(d), b.ptr, b.ld, b.c_pad, stream)
             best, best_ms = _fastest(range(1, self.lib.y5_conv_cat2_num_variants() + 1), launch)
             _TUNED[key], _TUNED_MS[key] = best or 0, best_ms
         return _TUNED[key]
@@ -443,10 +523,11 @@ class Plan:
         best, best_ms = 0, float('inf')
         if self.lib.y5_conv_chain_f16(C.byref(d1), C.byref(d2), keep_first, 0, stream) == 0:
             key = ('chain', keep_first, d1.batch, d1.h, d1.w_in, d1.cin, d1.x_ld, d1.cout, d1.ksize, d1.stride, bool(d1.res), d2.cin, d2.cout, d2.y_ld)
-            if key not in _TUNED and tune:
+            def launch(v):
+                return self.lib.y5_conv_chain_f16(C.byref(d1), C.byref(d2), keep_first, v, stream)
+            if not _replay_ok(key, launch) and tune:
                 x1.buf.uniform_(-1.0, 1.0)
-                best, best_ms = _fastest(range(1, self.lib.y5_conv_chain_num_variants() + 1),
-                                         lambda v: self.lib.y5_conv_chain_f16(C.byref(d1), C.byref(d2), keep_first, v, stream))
+                best, best_ms = _fastest(range(1, self.lib.y5_conv_chain_num_variants() + 1), launch)
                 _TUNED[key], _TUNED_MS[key] = best or 0, best_ms
             best, best_ms = _TUNED.get(key, 0), _TUNED_MS.get(key, 0.0 if not tune else float('inf'))
         else:
@@ -480,15 +561,15 @@ class Plan:
             return 0
         key = (d.batch, d.h, d.w_in, d.cin, d.x_ld, d.cout, d.y_ld, d.ksize, d.stride, bool(d.res), bool(d.bias), bool(d.scale), d.dtype)
         self._last_key = key
-        if key in _TUNED:
-            return _TUNED[key]
-        x.buf.uniform_(-1.0, 1.0)
         stream = _lib.current_stream()
         nvar = self.lib.y5_conv_num_variants_bf16() if self.bf16 else self.lib.y5_conv_num_variants()
 
         def launch(v):
             d.variant = v
             return self.lib.y5_conv_f16(C.byref(d), stream)
+        if _replay_ok(key, launch):
+            return _TUNED[key]
+        x.buf.uniform_(-1.0, 1.0)
         best, best_t = _fastest(range(nvar + 1), launch)
         best = best or 0
         _TUNED[key] = best
@@ -943,10 +1024,13 @@ class Plan:
         stream = _lib.current_stream()
         key = ('csp1', x.batch, x.h, x.w, x.ld, out.ld, bool(b.add), m.cv1.bn is None)
         force = os.environ.get('Y5_CSP_FUSE') == 'force'
+        x.buf.uniform_(-1.0, 1.0)
+        if self.lib.y5_csp_f16(C.byref(d), stream) != 0:
+            # the launcher does not take this block (e.g. a post-op pattern that is neither all bias nor all scale +
+            # shift): the layer-by-layer plan does, whatever a cached choice or Y5_CSP_FUSE=force says
+            return False
         if os.environ.get('Y5_AUTOTUNE', '1') != '0' and key not in _TUNED and not force:
             # time the kernel against the layer-by-layer plan of the same block, recorded into a scratch plan
-            x.buf.uniform_(-1.0, 1.0)
-            _lib.check(self.lib.y5_csp_f16(C.byref(d), stream))
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(8):
@@ -1047,7 +1131,11 @@ class Plan:
         for bi, b in enumerate(bots[:-1] if chain else bots):
             nxt = self._new_act(x.batch, x.h, x.w, [(b.cv2.conv.out_channels, pad8(b.cv2.conv.out_channels))])
             if not link:
-                self._bottleneck('%s.m%d' % (name, bi), b, t, nxt)
+                if hidden is not None:  # this Bottleneck's cv1 already ran, chained to cv1 | cv2 above
+                    self._conv_block('%s.m%d.cv2' % (name, bi), b.cv2, hidden, nxt, res=t if b.add else None)
+                    hidden = None
+                else:
+                    self._bottleneck('%s.m%d' % (name, bi), b, t, nxt)
                 t = nxt
                 continue
             if hidden is None:
@@ -1297,6 +1385,13 @@ def run_block(module, x):
             plan.close()
 
 
+class _State:
+    """What a full walk of the model found, kept until something changes: the tensor list with its version counters and
+    addresses (the cheap per-forward comparison), the hook tables of every sub-module, and the facts eligibility needs."""
+    __slots__ = ('epoch', 'tensors', 'versions', 'ptrs', 'hook_tables', 'dtype', 'head', 'stride', 'stride_version', 'smax',
+                 'types_ok', 'signature')
+
+
 class Engine:
     """Per-model cache of launch plans keyed by input shape and by the identity/version of every parameter."""
 
@@ -1306,26 +1401,61 @@ class Engine:
         self.signature = None
         self.unsupported = None   # (signature, reason) of the last failed lowering
         self.calls = 0            # forwards executed by HIP kernels (read by tests)
+        self.walks = 0            # full walks of the model (tests: the steady state does none)
+        self._state = None
 
     @property
     def model(self):
         return self._model()
 
-    def _signature(self):
-        sig = []
-        for t in list(self.model.parameters()) + list(self.model.buffers()):
-            sig.append((id(t), t.data_ptr(), t._version, t.dtype))
-        head = self.model.model[-1]
-        sig.append(tuple(float(s) for s in head.stride) if head.stride is not None else None)
-        return hash(tuple(sig))
+    def _walk(self):
+        """Full walk of the model: O(modules + tensors).  Runs on the first forward and after anything was assigned to a
+        module anywhere in the process, a tensor was written in place or moved (version counter / address), or Detect's
+        stride attribute was replaced."""
+        from yolo_amd.models.yolo import Detect
+        model = self.model
+        st = _State()
+        st.epoch = _REG_EPOCH[0]
+        st.tensors = list(model.parameters()) + list(model.buffers())
+        st.versions = [t._version for t in st.tensors]
+        st.ptrs = [t.data_ptr() for t in st.tensors]
+        mods = list(model.modules())
+        st.hook_tables = [m._forward_hooks for m in mods] + [m._forward_pre_hooks for m in mods]
+        st.dtype = st.tensors[0].dtype if st.tensors else None
+        head = model.model[-1]
+        st.head = head if isinstance(head, Detect) else None
+        st.stride = getattr(head, 'stride', None)
+        st.stride_version = st.stride._version if isinstance(st.stride, torch.Tensor) else None
+        st.smax = int(max(st.stride)) if st.stride is not None else 32
+        st.types_ok = all(isinstance(m, _supported_types()) for m in model.model)
+        sig = [(id(t), p, v, t.dtype) for t, p, v in zip(st.tensors, st.ptrs, st.versions)]
+        sig.append(tuple(float(s) for s in st.stride) if st.stride is not None else None)
+        st.signature = hash(tuple(sig))
+        self.walks += 1
+        return st
 
-    def _plan(self, x):
-        sig = self._signature()
-        if sig != self.signature:
+    def state(self):
+        """The model's state, from the cache when nothing changed since the last walk."""
+        st = self._state
+        if st is not None and st.epoch == _REG_EPOCH[0]:
+            ts = st.tensors
+            stride = getattr(self.model.model[-1], 'stride', None)
+            if (stride is st.stride and (st.stride_version is None or stride._version == st.stride_version)
+                    and [t._version for t in ts] == st.versions and [t.data_ptr() for t in ts] == st.ptrs):
+                return st
+        st = self._state = self._walk()
+        if st.signature != self.signature:
             for p in self.plans.values():
                 p.close()
             self.plans.clear()
-            self.signature = sig
+            self.signature = st.signature
+        return st
+
+    def _signature(self):
+        return self.state().signature
+
+    def _plan(self, x, st=None):
+        sig = (st or self.state()).signature
         key = (tuple(x.shape), x.device.index, x.dtype, input_layout(x))
         plan = self.plans.get(key)
         if plan is None:
@@ -1347,21 +1477,22 @@ class Engine:
         return plan
 
     def supported(self, x):
-        for m in self.model.model:
-            if not isinstance(m, _supported_types()):
-                return False
-        return self._plan(x) is not None
+        st = self.state()
+        return st.types_ok and self._plan(x, st) is not None
 
-    def forward(self, x):
-        plan = self._plan(x)
-        if plan is None:
-            raise _lib.Y5Error('model not supported by the HIP engine: %s' % (self.unsupported or ('', ''))[1])
+    def _run(self, plan, x):
         if not plan.hwc:
             x = x.contiguous()
         with torch.cuda.device(x.device):
             z, xs = plan.run(x)
         self.calls += 1
         return z, xs
+
+    def forward(self, x):
+        plan = self._plan(x)
+        if plan is None:
+            raise _lib.Y5Error('model not supported by the HIP engine: %s' % (self.unsupported or ('', ''))[1])
+        return self._run(plan, x)
 
     def profile(self, x):
         plan = self._plan(x)

@@ -100,6 +100,9 @@ class Model(nn.Module):
         if not augment:
             return self.forward_once(x, profile)
         # test-time augmentation: original, flipped+0.83x, 0.67x (reference: models/yolo.py:89-103)
+        if isinstance(x, torch.Tensor) and x.dtype is torch.uint8:
+            # the flipped / rescaled views below are new tensors: a from_hwc batch would lose its channel-order marking
+            raise TypeError('augment=True needs a floating-point batch (img.half() / 255.0); uint8 input is for plain forwards')
         height_width = x.shape[-2:]
         scales = (0.83, 0.67)
         views = (x, torch_utils.scale_img(x.flip(3), scales[0]), torch_utils.scale_img(x, scales[1]))
@@ -111,14 +114,18 @@ class Model(nn.Module):
 
     def forward_once(self, x, profile=False):
         from yolo_amd import engine
-        if not profile and engine.eligible(self, x):
-            return engine.run(self, x)
+        if not profile:
+            out = engine.try_run(self, x)
+            if out is not None:
+                return out
         if isinstance(x, torch.Tensor) and x.dtype is torch.uint8:  # same convenience off the engine: test.py:152-154
-            if getattr(x, 'y5_bgr', False):  # yolo_amd.preprocess.from_hwc(..., bgr=True): utils/datasets.py:140
+            if engine.input_layout(x) == engine._lib.IN_U8_HWC_BGR:  # yolo_amd.preprocess.from_hwc(..., bgr=True): utils/datasets.py:140
                 x = x.flip(1)
             x = x.to(next(self.parameters()).dtype) / 255.0
-            if not profile and engine.eligible(self, x):
-                return engine.run(self, x)
+            if not profile:
+                out = engine.try_run(self, x)
+                if out is not None:
+                    return out
         return self._forward_modules(x, profile)
 
     def _forward_modules(self, x, profile=False):

@@ -35,7 +35,8 @@ def nms_padded(prediction, conf_thres=0.1, iou_thres=0.6, classes=None, agnostic
     n_candidates yourself) to stay asynchronous.
 
     stream: a torch.cuda.Stream to run the pipeline on instead of the current one.  The call is ordered after the work
-    already issued on the current stream (the forward that produced `prediction`) and returns at once; the current
+    already issued on the current stream (the forward that produced `prediction`) and, with check_overflow=False,
+    returns at once (with check_overflow the host waits for `stream` to read the candidate totals); the current
     stream does NOT wait for it, so a following forward of the next batch runs beside this NMS (its kernels are small
     and leave most of the chip idle).  The results belong to `stream`: make the consumer wait for it
     (torch.cuda.current_stream().wait_stream(stream), or stream.synchronize()) before reading them.
@@ -76,11 +77,12 @@ def nms_padded(prediction, conf_thres=0.1, iou_thres=0.6, classes=None, agnostic
             d.agnostic = 1 if agnostic else 0
             d.max_candidates, d.max_det = cap, max_det
             _lib.check(lib.y5_nms_batched(C.byref(d), _lib.current_stream()))
-        if check_overflow:
-            worst = int(ncand.max().item())
-            if worst > cap:
-                cap = worst
-                continue
+            # the candidate totals are read back on the stream that computed them (inside this context the reduction
+            # and the copy are ordered after the kernels; on the caller's stream they could run before them)
+            worst = int(ncand.max().item()) if check_overflow else 0
+        if worst > cap:
+            cap = worst
+            continue
         break
     return (det, count, kept, ncand) if return_index else (det, count)
 
