@@ -156,8 +156,12 @@ def main():
     # still computes its own forward, decode, NMS (and exchange); fence() waits for both streams.
     side = None if args.serial_nms else torch.cuda.Stream(device)
 
-    def step():
+    def step(events=None):
+        if events is not None:
+            events[0].record()
         z, _ = model(x)
+        if events is not None:
+            events[1].record()
         det, count, kept, ncand = hip_nms.nms_padded(z, args.conf, args.iou, return_index=True, check_overflow=False, stream=side)
         if world > 1:
             with torch.cuda.stream(side):
@@ -176,16 +180,29 @@ def main():
     eng = engine.engine_of(model)
     if eng.calls < args.warmup:
         raise SystemExit('bench: forward did not run on the HIP engine')
+    # Inside the timed loop: an event pair around every forward on the stream it is launched on (the device time of the
+    # forward as the timed steps ran it, NMS of the previous step beside it) and the host's wall time inside step() (what
+    # the Python + launch path costs per step; the device queue is never full, so step() does not wait for the GPU).
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    host_s = 0.0
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    for i in range(args.steps):
+        h0 = time.perf_counter()
+        out = step(ev[i])
+        host_s += time.perf_counter() - h0
     fence()
     elapsed = time.perf_counter() - t0
+    loop_forward_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    host_enqueue_ms = host_s / args.steps * 1e3
+    rank_ms = [elapsed / args.steps * 1e3]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if dist.get_backend() == 'gloo' else device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        cdev = 'cpu' if dist.get_backend() == 'gloo' else device
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        rank_ms = [float(e.item()) / args.steps * 1e3 for e in every]
+        elapsed = max(float(e.item()) for e in every)   # MAX over ranks
     det, count, ncand = out
     if det.shape[0] != global_batch:
         raise SystemExit('bench: gathered %d images, expected %d' % (det.shape[0], global_batch))
@@ -230,7 +247,9 @@ def main():
         f1.record()
         torch.cuda.synchronize()
         forward_ms = f0.elapsed_time(f1) / args.profile_passes
-        event_scale = min(1.0, forward_ms / sum(a['ms'] for a in acc))
+        # the per-op durations are scaled to the forward as the TIMED steps ran it (event pairs inside the loop), so the
+        # roofline's denominator is a share of ms_per_step and cannot exceed it
+        event_scale = loop_forward_ms / sum(a['ms'] for a in acc)
         for a in acc:
             a['ms'] *= event_scale
         det = [a for a in acc if a['kind'] == 'detect']  # Detect levels as one kernel each: head conv with the decode as its epilogue
@@ -260,11 +279,29 @@ def main():
         gbs = conv_bytes / (conv_ms * 1e-3) / 1e9
         # which roof binds the convolution work of this model: its FLOP/byte against the machine's
         hbm_bound = conv_bytes / (PEAK_HBM_GBS * 1e9) >= conv_flops / (PEAK_MFMA_TFLOPS * 1e12)
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'r2_hbm_traffic.json')  # written by tools/round_profile.sh on this plan
-        if os.path.exists(tpath) and args.model == 'yolov5s' and args.batch == 32:
+        # HBM bytes of the same launches from rocprofv3's counters (FETCH_SIZE x 2 + WRITE_SIZE, separate passes): they
+        # cannot be collected inside this process, so the figure is the one tools/round_profile.sh measured for this
+        # workload and committed, named with its source; null when no such file matches the workload
+        traffic, traffic_source = None, None
+        tpath = os.path.join(ROOT, 'profiles', 'r3_hbm_traffic.json')
+        if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get('conv_total')  # rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of the same launches
+                tj = json.load(f)
+            if tj.get('model', 'yolov5s') == args.model and tj.get('batch', 32) == args.batch:
+                traffic = tj.get('conv_total')
+                traffic_source = 'profiles/r3_hbm_traffic.json: %s' % tj.get('source', 'tools/round_profile.sh, another process on another box')
+        # B = 1 latency (detect.py's case): forward + NMS + host synchronisation per image, median of 30
+        x1 = x[:1].contiguous()
+        lat = []
+        for i in range(35):
+            torch.cuda.synchronize()
+            l0 = time.perf_counter()
+            z1, _ = model(x1)
+            hip_nms.nms_padded(z1, args.conf, args.iou, check_overflow=False)
+            torch.cuda.synchronize()
+            lat.append((time.perf_counter() - l0) * 1e3)
+        lat = sorted(lat[5:])
+        latency_b1_ms = lat[len(lat) // 2]
         top = sorted(conv, key=lambda a: -a['ms'])[:6]
         roofline = {'kernel': 'convolution kernels (stem2 / csp1 / conv_c64 / conv_c128 / conv_s2c64 / conv_p1x1 / conv_p1x1_cat / conv_igemm / conv_lw / conv_lin3 / conv_ws1x1 / conv3x3_ws / detect_p): all %d launches of one forward'
                               % len(conv),
@@ -272,6 +309,8 @@ def main():
                     'achieved': round(gbs if hbm_bound else tflops, 2), 'peak': PEAK_HBM_GBS if hbm_bound else PEAK_MFMA_TFLOPS,
                     'unit': 'GB/s' if hbm_bound else 'TFLOP/s',
                     'frac': round(gbs / PEAK_HBM_GBS if hbm_bound else tflops / PEAK_MFMA_TFLOPS, 4), 'traffic': traffic,
+                    'traffic_source': traffic_source,
+                    'frac_plan_bytes': round(plan_bytes / (conv_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                     'bytes_per_forward': conv_bytes, 'bytes_basis': 'every Conv2d of the graph as one kernel (in + out + weights, fp16)' + (' + decode read/write of the head' if det else ''),
                     'plan_bytes_per_forward': plan_bytes, 'flops_per_forward': conv_flops, 'layer_list_flops': ref_flops, 'ms_per_forward': round(conv_ms, 4),
                     'mfma_tflops': round(tflops, 2), 'mfma_frac': round(tflops / PEAK_MFMA_TFLOPS, 4),
@@ -279,6 +318,8 @@ def main():
         record = {
             'metric': 'images/sec at 640x640 fp16 (conv fwd+decode+NMS)', 'value': round(value, 1), 'unit': 'images/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_step, 4),
+            'host_enqueue_ms_per_step': round(host_enqueue_ms, 4), 'forward_ms_in_loop': round(loop_forward_ms, 4),
+            'latency_batch1_ms': round(latency_b1_ms, 4), 'rank_ms_per_step': {'min': round(min(rank_ms), 4), 'max': round(max(rank_ms), 4)},
             'higher_is_better': True, 'scaling': 'strong' if args.global_batch else 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
             'config': {'workload': '%s 640x640 fp16 batch %d per GPU, conf %g iou %g (test.py setting), random-init weights, '
                                    'BatchNorm-calibrated, head gain %g' % (args.model, args.batch, args.conf, args.iou, args.head_gain),
@@ -287,7 +328,7 @@ def main():
                        'candidates_per_image': round(cand, 1), 'kept_per_image': round(kept, 1),
                        'nms_stream': 'same stream as the forward' if side is None else 'second stream: NMS of step i beside the forward of step i+1'},
             'roofline': roofline,
-            'stages': {'note': 'each stage timed on its own after the timed loop (one stream, nothing overlapped): they do not sum to ms_per_step',
+            'stages': {'note': 'forward_ms and nms_ms are timed on their own after the timed loop (one stream, nothing overlapped); plan_ms / conv_ms / decode_ms are per-launch event durations scaled to sum to forward_ms_in_loop',
                        'forward_ms': round(forward_ms, 4), 'plan_ms': round(plan_ms, 4), 'conv_ms': round(conv_ms, 4), 'decode_ms': round(dec_ms, 4), 'decode_kernels': 'head conv + decode fused' if det else 'decode',
                        'nms_ms': round(nms_ms, 4),
                        'decode_hbm': {'bound': 'hbm', 'achieved': round(dec_bytes / (dec_ms * 1e-3) / 1e9, 1), 'peak': PEAK_HBM_GBS,

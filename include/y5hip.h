@@ -84,8 +84,8 @@ typedef struct y5_conv_desc {
     int32_t variant;            /* 0 = tile configuration chosen by rule; 1..y5_conv_num_variants() = explicit   */
     int32_t dtype;              /* Y5_F16 (0) or Y5_BF16: element type of x, w, res and y.  bf16 (the reference's modules
                                  * under .bfloat16(): same operations, bfloat16 roundings) is served by y5_conv_f16 with the
-                                 * im2col kernel family only: variant 0 or the first y5_conv_num_variants_bf16() ids; every
-                                 * other entry point that takes this descriptor wants Y5_F16 */
+                                 * im2col kernel family and the phased kernels: variant 0 or ids 1..y5_conv_num_variants_bf16();
+                                 * every other entry point that takes this descriptor wants Y5_F16 */
 } y5_conv_desc;
 
 int y5_conv_f16(const y5_conv_desc* d, y5_stream_t stream);
@@ -93,8 +93,13 @@ int y5_conv_f16(const y5_conv_desc* d, y5_stream_t stream);
  * loader-wave kernel families), for autotuning the `variant` field: time each id on the real shape and keep the
  * fastest; an id that does not apply to the shape returns Y5_EINVAL. */
 int y5_conv_num_variants(void);
-/* Number of tile configurations compiled for Y5_BF16 (ids 1..n of the variant field when dtype is Y5_BF16). */
+/* Number of kernel variants compiled for Y5_BF16 (ids 1..n of the variant field when dtype is Y5_BF16): the im2col tile
+ * configurations, then the phased kernels. */
 int y5_conv_num_variants_bf16(void);
+/* Number of phased implicit-GEMM kernels (the compute-bound layers of models/common.py:18-30 at the widths
+ * models/yolo.py:195 produces for yolov5m / l / x): the LAST ids of y5_conv_num_variants() and of
+ * y5_conv_num_variants_bf16(). */
+int y5_conv_num_variants_phased(void);
 
 /* Two convolutions in one kernel: `first` (3x3, or 1x1 stride 1; all post-ops of y5_conv_f16 including the residual)
  * followed by `second`, a 1x1 stride-1 convolution of first's output (bias / scale+shift / activation, no residual):

@@ -243,14 +243,17 @@ def test_every_kernel_variant_that_takes_the_shape(dev, shape):
         if got is not None:  # some kernel families take no residual input
             close_ulp(got, ref_res, mags=bn_mags + (pre, res), slack=order * sv.abs())
     assert taken >= 10
+    nph = _lib.lib().y5_conv_num_variants_phased()   # the phased kernels are the last ids and take every shape
+    nv = _lib.lib().y5_conv_num_variants() - nph
+    for v in range(nv + 1, nv + nph + 1):
+        assert run_conv(dev, x, w, bias=bias, slope=0.1, stride=s, variant=v) is not None, 'the phased kernels take every 1x1 / 3x3 shape'
     if (Ci, Co, k, s) == (32, 64, 3, 2) and (H // 2) % 8 == 0 and (W // 2) % 16 == 0:
-        assert run_conv(dev, x, w, bias=bias, slope=0.1, stride=s, variant=_lib.lib().y5_conv_num_variants()) is not None, 'the persistent stride-2 kernel takes this shape'
+        assert run_conv(dev, x, w, bias=bias, slope=0.1, stride=s, variant=nv) is not None, 'the persistent stride-2 kernel takes this shape'
     if k == 1 and Ci in (128, 256) and Co in (128, 256):
-        nv = _lib.lib().y5_conv_num_variants()
         assert run_conv(dev, x, w, bias=bias, slope=0.1, stride=s, variant=nv - 3) is not None, 'the persistent 1x1 kernel takes this shape'
         assert (run_conv(dev, x, w, bias=bias, slope=0.1, stride=s, variant=nv - 4) is not None) == ((Ci, Co) != (256, 128))
     if (Ci, Co, k, s) == (64, 128, 3, 2) and (H // 2) % 4 == 0 and (W // 2) % 16 == 0:
-        assert run_conv(dev, x, w, bias=bias, slope=0.1, stride=s, variant=_lib.lib().y5_conv_num_variants() - 2) is not None, 'the persistent 64-channel stride-2 kernel takes this shape'
+        assert run_conv(dev, x, w, bias=bias, slope=0.1, stride=s, variant=nv - 2) is not None, 'the persistent 64-channel stride-2 kernel takes this shape'
 
 
 @pytest.mark.parametrize('shape', [(2, 64, 96, 32), (3, 42, 74, 32), (1, 128, 66, 48), (2, 36, 130, 80), (1, 640, 640, 32)],

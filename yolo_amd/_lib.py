@@ -78,6 +78,7 @@ SIGNATURES = {
     'y5_csp_f16': (_i, [C.POINTER(CspDesc), _s]),
     'y5_plan_add_csp': (_i, [_p, C.POINTER(CspDesc)]),
     'y5_conv_num_variants_bf16': (_i, []),
+    'y5_conv_num_variants_phased': (_i, []),
     'y5_pack_image_f16': (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _s]),
     'y5_maxpool_f16': (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _s]),
     'y5_maxpool_cascade_f16': (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _s]),

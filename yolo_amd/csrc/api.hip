@@ -78,6 +78,7 @@ extern "C" int y5_normalize_u8_f16(const void* x, void* y, int64_t n, y5_stream_
 }
 extern "C" int y5_conv_num_variants(void) { return y5_conv_variant_count(); }
 extern "C" int y5_conv_num_variants_bf16(void) { return y5_conv_bf16_variant_count(); }
+extern "C" int y5_conv_num_variants_phased(void) { return y5_conv_ph_count(); }
 extern "C" int y5_pack_image_f16(const void* x, void* y, int batch, int c, int h, int w, int focus, int y_ld,
                                  y5_stream_t stream) {
     return y5_launch_pack_image(x, y, batch, c, h, w, focus, y_ld, static_cast<hipStream_t>(stream));

@@ -537,9 +537,20 @@ int y5_launch_conv(const y5_conv_desc& d, hipStream_t s, const Y5ConvStats* st) 
     const bool bf = d.dtype == Y5_BF16;
     if (bf) {
         Y5_REQUIRE(!st, "conv: statistics are accumulated for fp16 tensors only");
-        if (d.variant > kNumBf) return y5_fail(Y5_EINVAL, "conv: variant %d is not compiled for bf16 (1..%d are)", d.variant, kNumBf);
+        if (d.variant > kNumBf + y5_conv_ph_count()) return y5_fail(Y5_EINVAL, "conv: variant %d is not compiled for bf16 (1..%d are)", d.variant, kNumBf + y5_conv_ph_count());
+        if (d.variant > kNumBf) {  // the phased kernels (conv_ph.hip) follow the im2col tile configurations
+            int rc = Y5_OK;
+            if (y5_try_conv_ph(d, s, d.variant - kNumBf, &rc)) return rc;
+            return y5_fail(Y5_EINVAL, "conv: the phased variant %d does not apply to this shape", d.variant);
+        }
     }
     Y5_REQUIRE(d.variant >= 0 && d.variant <= y5_conv_variant_count(), "conv: variant %d out of range 0..%d", d.variant, y5_conv_variant_count());
+    if (d.variant > y5_conv_variant_count() - y5_conv_ph_count()) {  // the phased kernels (conv_ph.hip) come last
+        Y5_REQUIRE(!st, "conv: variant %d does not accumulate statistics", d.variant);
+        int rc = Y5_OK;
+        if (y5_try_conv_ph(d, s, d.variant - (y5_conv_variant_count() - y5_conv_ph_count()), &rc)) return rc;
+        return y5_fail(Y5_EINVAL, "conv: the phased variant %d does not apply to this shape", d.variant);
+    }
     if (st) {
         Y5_REQUIRE(st->partials && st->rows > 0 && st->c > 0 && st->off >= 0 && st->off + d.cout <= st->c, "conv: statistics columns %d..+%d outside 0..%d (rows %d)", st->off, d.cout, st->c, st->rows);
         Y5_REQUIRE((reinterpret_cast<uintptr_t>(st->partials) & 3) == 0, "conv: misaligned statistics pointer");
@@ -662,10 +673,10 @@ int y5_launch_conv(const y5_conv_desc& d, hipStream_t s, const Y5ConvStats* st) 
     return table[v].launch(a, d.ksize, direct, s);
 }
 
-int y5_conv_variant_count() { return kNumIgemm + kNumHalo + kNumWs + kNumWs3 + y5_conv_lw_count() + y5_conv_lin_count() + y5_conv_p1x1_count() + y5_conv_s2c64_count() + y5_conv_s2c32_count(); }
+int y5_conv_variant_count() { return kNumIgemm + kNumHalo + kNumWs + kNumWs3 + y5_conv_lw_count() + y5_conv_lin_count() + y5_conv_p1x1_count() + y5_conv_s2c64_count() + y5_conv_s2c32_count() + y5_conv_ph_count(); }
 
 int y5_conv_cat2_variant_count() { return kNumCat2 + 1; }  // the tile configurations, then the persistent kernel (conv_p1x1.hip)
-int y5_conv_bf16_variant_count() { return kNumBf; }
+int y5_conv_bf16_variant_count() { return kNumBf + y5_conv_ph_count(); }
 
 // d: the convolution with x = the half-resolution tensor (batch, ho/2, wo/2, cin), h = ho, w_in = wo the OUTPUT
 // resolution; x2 (batch, ho, wo, cin2).  Weight rows hold K = cin + cin2 values, x's channels first.

@@ -138,6 +138,10 @@ int y5_launch_conv_chain(const y5_conv_desc& f, const y5_conv_desc& g, int keep_
 int y5_try_conv_c64_chain(const y5_conv_desc& f, const y5_conv_desc& g, int keep_first, hipStream_t s, int* rc);
 int y5_try_conv_c128_chain(const y5_conv_desc& f, const y5_conv_desc& g, int keep_first, hipStream_t s, int* rc);
 int y5_conv_variant_count();
+// phased implicit-GEMM kernels for the compute-bound layers (conv_ph.hip): the last fp16 variants, and the bf16 variants
+// behind the im2col tile configurations
+int y5_try_conv_ph(const y5_conv_desc& d, hipStream_t s, int which, int* rc);
+int y5_conv_ph_count();
 // BottleneckCSP with one Bottleneck as one kernel (conv_csp.hip)
 int y5_launch_csp(const y5_csp_desc& d, hipStream_t s);
 int y5_conv_bf16_variant_count();

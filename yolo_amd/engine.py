@@ -557,10 +557,10 @@ class Plan:
         """Pick the fastest compiled tile configuration for this convolution by timing every applicable one on
         the real shape (random activations, the layer's own weights).  Results are cached per shape for the
         process; Y5_AUTOTUNE=0 keeps the rule-based choice (variant 0)."""
-        if os.environ.get('Y5_AUTOTUNE', '1') == '0':
-            return 0
         key = (d.batch, d.h, d.w_in, d.cin, d.x_ld, d.cout, d.y_ld, d.ksize, d.stride, bool(d.res), bool(d.bias), bool(d.scale), d.dtype)
         self._last_key = key
+        if os.environ.get('Y5_AUTOTUNE', '1') == '0':
+            return 0
         stream = _lib.current_stream()
         nvar = self.lib.y5_conv_num_variants_bf16() if self.bf16 else self.lib.y5_conv_num_variants()
 
