@@ -9,7 +9,8 @@ from yolo_amd import _lib
 
 dev = torch.device('cuda:0')
 lib = _lib.lib()
-NV, NPH = lib.y5_conv_num_variants(), lib.y5_conv_num_variants_phased()
+NV = lib.y5_conv_num_variants()
+NPH = int(os.environ.get('NEW_VARIANTS', '12'))  # the pixel-resident (conv_pr.hip) and phased (conv_ph.hip) kernels: the last ids
 
 
 def setup(B, Ci, Co, H, W, k, s, seed=0):
@@ -41,7 +42,8 @@ def setup(B, Ci, Co, H, W, k, s, seed=0):
 
 def check():
     shapes = [(1, 64, 64, 8, 8, 1, 1), (2, 64, 128, 20, 20, 3, 1), (3, 80, 96, 17, 23, 3, 1), (2, 128, 255, 20, 12, 1, 1),
-              (2, 40, 72, 17, 33, 3, 2), (1, 256, 512, 20, 20, 3, 2), (5, 13, 25, 9, 7, 3, 1), (2, 320, 320, 40, 40, 3, 1)]
+              (2, 40, 72, 17, 33, 3, 2), (1, 256, 512, 20, 20, 3, 2), (5, 13, 25, 9, 7, 3, 1), (2, 320, 320, 40, 40, 3, 1),
+              (3, 128, 128, 80, 80, 3, 1), (7, 64, 200, 33, 47, 3, 1), (2, 160, 96, 19, 20, 3, 1)]
     st = _lib.current_stream()
     for shp in shapes:
         B, Ci, Co, H, W, k, s = shp
@@ -51,7 +53,8 @@ def check():
         for v in range(NV - NPH + 1, NV + 1):
             y.fill_(float('nan'))
             d.variant = v
-            _lib.check(lib.y5_conv_f16(C.byref(d), st))
+            if lib.y5_conv_f16(C.byref(d), st) == _lib.EINVAL:
+                continue
             torch.cuda.synchronize()
             got = y[..., :Co].permute(0, 3, 1, 2)
             bad = torch.isnan(y).any().item()

@@ -205,3 +205,17 @@ __device__ __forceinline__ f16x4 post_op4(f32x4 v, int n, const ConvArgs& a) {
     return leaky4_f16(h, a.slope);
 }
 
+
+// v_mfma_f32_16x16x32: D (16 x 16, lane l holds column l & 15, rows 4 * (l >> 4) .. + 3) += A (16 x 32, lane l: row l & 15,
+// k = 8 * (l >> 4) .. + 7) * B (32 x 16, lane l: column l & 15, the same k).
+template <typename ET>
+struct Mma16;
+template <>
+struct Mma16<f16> {
+    static __device__ __forceinline__ f32x4 run(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <>
+struct Mma16<bf16> {
+    static __device__ __forceinline__ f32x4 run(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+

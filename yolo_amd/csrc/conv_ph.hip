@@ -18,33 +18,40 @@
 // every wave has passed after its own wait.  WAR: a slot is refilled one phase after its last read, and every phase
 // drains its reads (lgkmcnt(0)) before its first barrier.  K-tiles past the end are "issued" with out-of-range offsets
 // (the descriptor's range check turns them into zero fills of free slots), which keeps the wait count constant.
+#include <type_traits>
+
 #include "y5_common.h"
 
 namespace {
 
 #include "conv_common.h"
 
-template <typename ET>
-struct Mma16;
-template <>
-struct Mma16<f16> {
-    static __device__ __forceinline__ f32x4 run(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-};
-template <>
-struct Mma16<bf16> {
-    static __device__ __forceinline__ f32x4 run(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-};
+// dma16_buf (conv_common.h) leaving M0 set to the copy's LDS address instead of restoring it: two scalar moves fewer per copy where copy
+// issue is what a kernel's phases wait for (the compiler is told that M0 is overwritten).
+__device__ __forceinline__ void dma16_buf_m0(i32x4 rsrc, unsigned voff, unsigned lds_base) {
+    asm volatile(
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %0, %1, 0 offen lds"
+        :
+        : "v"(voff), "s"(rsrc), "s"(lds_base)
+        : "memory", "m0");
+}
 
-// WM x WN waves (eight), each owning MF x NF accumulators of 16 pixels x 16 channels: tile = (WM*MF*16) pixels x
-// (WN*NF*16) channels.  MF and NF pick the tile that fills the chip in whole rounds for a layer's pixel and channel
+
+// WM x WN waves (eight), each owning MF x NF accumulators of TS pixels x TS channels (TS = 16: v_mfma_f32_16x16x32, two per
+// 64-wide K-tile and accumulator; TS = 32: v_mfma_f32_32x32x16, four): tile = (WM*MF*TS) pixels x (WN*NF*TS) channels.
+// The 32 x 32 form holds a SIMD's instruction issue for 8 of its 32 cycles, the 16 x 16 form for 8 of 16: beside a partner
+// wave that has ~60 address / read / copy instructions to issue per phase, the wide form leaves it the slots it needs.  MF and NF pick the tile that fills the chip in whole rounds for a layer's pixel and channel
 // counts (the engine times the compiled shapes per layer); the halves of the schedule hold ceil / floor of them.
-template <int WM, int WN, int MF, int NF>
+template <int WM, int WN, int MF, int NF, int TS>
 struct PhCfg {
     static_assert(WM * WN == 8, "eight waves");
-    static_assert(MF >= 2 && MF <= 8 && NF >= 2 && NF <= 6 && MF * NF <= 32, "at most 128 accumulator registers");
+    static_assert(TS == 16 || TS == 32, "MFMA tile");
+    static_assert(MF >= 2 && NF >= 2 && MF * NF * TS * TS <= 32 * 256, "at most 128 accumulator registers");
     static constexpr int MF0 = (MF + 1) / 2, MF1 = MF / 2, NF0 = (NF + 1) / 2, NF1 = NF / 2;
-    static constexpr int BM = WM * MF * 16, BN = WN * NF * 16;
-    static constexpr int PR = MF0 * 16, WR = NF0 * 16;            // rows a wave row / wave column owns in a slot
+    static constexpr int BM = WM * MF * TS, BN = WN * NF * TS;
+    static constexpr int PR = MF0 * TS, WR = NF0 * TS;            // rows a wave row / wave column owns in a slot
     static constexpr int P_SLOT = WM * PR * 128, W_SLOT = WN * WR * 128;  // bytes (128-byte rows)
     static constexpr int P_PIECES = WM * PR / 8, W_PIECES = WN * WR / 8;  // 1 KiB DMA pieces per half-tile
     static constexpr int NP = (P_PIECES + 7) / 8, NW = (W_PIECES + 7) / 8;  // DMA instructions per thread and half-tile
@@ -57,19 +64,40 @@ struct PhCfg {
     static_assert(SMEM <= 160 * 1024, "one workgroup per compute unit");
 };
 
+#ifdef Y5_STAMPS
+// Diagnostic build only (make dbg): per workgroup and tile, wave 0: {start, set-up done, K-tile 0 landed, K loop end, tile
+// staged, stores issued} in shader cycles, then the 100 MHz real-time counter at start and end
+__device__ unsigned long long y5_ph_stamp_buf[8 * 65536];
+#define PH_STAMP(I) if (t == 0 && stamp_row < 65536) y5_ph_stamp_buf[8 * stamp_row + (I)] = __builtin_amdgcn_s_memtime();
+// K-loop sections of waves 0 and 4, summed over the K-tiles of a tile: {issue + reads, vmcnt wait, lgkmcnt wait + barrier,
+// MFMAs, second barrier}
+__device__ unsigned long long y5_ph_sect_buf[2 * 8 * 65536];
+#define PH_SECT(I) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); sect[I] += now_ - sect_t; sect_t = now_; }
+#define PH_RSTAMP(I) if (t == 0 && stamp_row < 65536) y5_ph_stamp_buf[8 * stamp_row + (I)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define PH_STAMP(I)
+#define PH_RSTAMP(I)
+#define PH_SECT(I)
+#endif
+
 #define PH_SYNC_READS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define PH_BARRIER() asm volatile("s_barrier" ::: "memory")
 
-template <typename ET, int WM, int WN, int MF, int NF>
+// UNI: Cin is a multiple of 64, so a K-tile lies in one tap: its tap, validity bit and source offset are wave-uniform
+// (scalar arithmetic) instead of per lane.
+template <typename ET, int WM, int WN, int MF, int NF, int TS, bool UNI>
 __global__ __launch_bounds__(512, 2) void conv_ph_kernel(const ConvArgs a_unused) {
-    typedef PhCfg<WM, WN, MF, NF> Cfg;
+    typedef PhCfg<WM, WN, MF, NF, TS> Cfg;
+    constexpr int KSN = TS == 16 ? 2 : 4;   // MFMA K-steps per 64-wide K-tile
+    constexpr int FB = TS * 128;            // bytes of one fragment's rows in a slot
+    typedef typename std::conditional<TS == 16, f32x4, f32x16>::type accv;
     typedef typename Elem<ET>::v8 ev8;
     typedef typename Elem<ET>::v4 ev4;
     constexpr int MF0 = Cfg::MF0, MF1 = Cfg::MF1, NF0 = Cfg::NF0, NF1 = Cfg::NF1;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, EP = Cfg::EP, PR = Cfg::PR, WR = Cfg::WR;
     constexpr int P_SLOT = Cfg::P_SLOT, W_SLOT = Cfg::W_SLOT, W_RING = 4 * P_SLOT;
     constexpr int NP = Cfg::NP, NW = Cfg::NW;
-    constexpr int VM = 2 * NP + NW;           // three half-tiles (P, W, P) stay in flight at the wait of a K-tile
+    constexpr int VM = 2 * NP + 2 * NW;       // four half-tiles (P1, P0, W0, W1) stay in flight at the wait of a phase
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
     const int t = threadIdx.x;
@@ -98,38 +126,48 @@ __global__ __launch_bounds__(512, 2) void conv_ph_kernel(const ConvArgs a_unused
     const i32x4 xr = make_buf(a.x, a.x_bytes), wr = make_buf(a.w, a.w_bytes);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     // ---- fragment addressing: lane l reads row (l & 15) of a 16-row group, K-chunk 4*ks + (l >> 4), at slot chunk ^ f(row)
-    const int lr = lane & 15, lq = lane >> 4;
-    const int sw = lr >> 1;  // f(row): the groups start at multiples of 16 rows
-    const int coff0 = ((lq ^ sw) << 4), coff1 = (((4 + lq) ^ sw) << 4);
+    // (TS = 32: row l & 31, K-chunk 2*ks + (l >> 5))
+    const int lr = lane & (TS - 1), lq = lane / TS;
+    const int sw = (lr >> 1) & 7;  // f(row): the groups start at multiples of 16 rows
+    int coff[KSN];
+#pragma unroll
+    for (int ks = 0; ks < KSN; ++ks) coff[ks] = ((((64 / TS) * ks + lq) ^ sw) << 4);
     const unsigned char* prow = smem + (wm * PR + lr) * 128;
     const unsigned char* wrow = smem + W_RING + (wn * WR + lr) * 128;
     float* prm = reinterpret_cast<float*>(smem + Cfg::TILE);
 
 #define PH_READ_P(SLOT, N)                                                                           \
-    _Pragma("unroll") for (int i = 0; i < (N); ++i) {                                                \
-        pf[i][0] = *reinterpret_cast<const ev8*>(prow + (SLOT) * P_SLOT + i * 2048 + coff0);         \
-        pf[i][1] = *reinterpret_cast<const ev8*>(prow + (SLOT) * P_SLOT + i * 2048 + coff1);         \
-    }
-#define PH_READ_W(WF, SLOT, N)                                                                       \
-    _Pragma("unroll") for (int j = 0; j < (N); ++j) {                                                \
-        WF[j][0] = *reinterpret_cast<const ev8*>(wrow + (SLOT) * W_SLOT + j * 2048 + coff0);         \
-        WF[j][1] = *reinterpret_cast<const ev8*>(wrow + (SLOT) * W_SLOT + j * 2048 + coff1);         \
-    }
-#define PH_MMA(M0, MN, N0, NN, WF)                                                                   \
+    _Pragma("unroll") for (int i = 0; i < (N); ++i)                                                  \
+        _Pragma("unroll") for (int ks = 0; ks < KSN; ++ks)                                           \
+            pf[i][ks] = *reinterpret_cast<const ev8*>(prow + (SLOT) * P_SLOT + i * FB + coff[ks]);
+#define PH_READ_W(J0, SLOT, N)                                                                       \
+    _Pragma("unroll") for (int j = 0; j < (N); ++j)                                                  \
+        _Pragma("unroll") for (int ks = 0; ks < KSN; ++ks)                                           \
+            wf[(J0) + j][ks] = *reinterpret_cast<const ev8*>(wrow + (SLOT) * W_SLOT + j * FB + coff[ks]);
+#define PH_MMA(M0, MN)                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                               \
     __builtin_amdgcn_s_setprio(1);                                                                   \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                 \
+    _Pragma("unroll") for (int ks = 0; ks < KSN; ++ks)                                               \
         _Pragma("unroll") for (int i = 0; i < (MN); ++i)                                             \
-            _Pragma("unroll") for (int j = 0; j < (NN); ++j)                                         \
-                acc[(M0) + i][(N0) + j] = Mma16<ET>::run(WF[j][ks], pf[i][ks], acc[(M0) + i][(N0) + j]); \
+            _Pragma("unroll") for (int j = 0; j < NF; ++j)                                           \
+                acc[(M0) + i][j] = mma(wf[j][ks], pf[i][ks], acc[(M0) + i][j]);                      \
     __builtin_amdgcn_s_setprio(0);                                                                   \
     __builtin_amdgcn_sched_barrier(0);
 
+    auto mma = [](ev8 w, ev8 p, accv c) -> accv {
+        if constexpr (TS == 16) return Mma16<ET>::run(w, p, c);
+        else return Elem<ET>::mfma(w, p, c);
+    };
     // persistent: a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...
     for (int it = blockIdx.x; it < tiles_total; it += gridDim.x) {
         const int tile = xcd_remap(it, tiles_total);
         const int mt = tile / tiles_n, nt = tile - mt * tiles_n;
         const int m0 = mt * BM, n0 = nt * BN;
+#ifdef Y5_STAMPS
+        const int stamp_row = (int)blockIdx.x + (int)gridDim.x * ((it - (int)blockIdx.x) / (int)gridDim.x);
+#endif
+        PH_STAMP(0)
+        PH_RSTAMP(6)
         EpiParams epi = {0.f, 1.f, 0.f};  // in registers through the K loop, staged in LDS behind it
         {
             PH_ARGS(a)
@@ -159,14 +197,14 @@ __global__ __launch_bounds__(512, 2) void conv_ph_kernel(const ConvArgs a_unused
             const int wrow_ = r / PR, within = r - wrow_ * PR;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int m = m0 + wrow_ * (MF * 16) + h * (MF0 * 16) + within;  // its pixel
-                const bool mvalid = pin && within < (h ? MF1 : MF0) * 16 && m < a.M;
+                const int m = m0 + wrow_ * (MF * TS) + h * (MF0 * TS) + within;  // its pixel
+                const bool mvalid = pin && within < (h ? MF1 : MF0) * TS && m < a.M;
                 const unsigned mm = mvalid ? (unsigned)m : 0u;
                 const unsigned b = fdiv(mm, div_hw);
                 const unsigned rem = mm - b * (unsigned)(a.Ho * a.Wo);
                 const unsigned oy = fdiv(rem, div_wo), ox = rem - oy * (unsigned)a.Wo;
                 const int hi0 = (int)oy * a.stride - a.pad, wi0 = (int)ox * a.stride - a.pad;
-                pbase[h][i] = (((int)b * a.H + hi0) * a.W + wi0) * a.x_ld * 2;
+                pbase[h][i] = (((int)b * a.H + hi0) * a.W + wi0) * a.x_ld * 2 + (UNI ? kc * 16 : 0);
                 // taps inside the image: rows hi0 .. hi0+2 and columns wi0 .. wi0+2 (1x1: the pixel itself)
                 unsigned rows = 0, cols = 0;
                 const int span = a.pad ? 3 : 1;
@@ -186,31 +224,41 @@ __global__ __launch_bounds__(512, 2) void conv_ph_kernel(const ConvArgs a_unused
             const int wcol = r / WR, within = r - wcol * WR;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int n = n0 + wcol * (NF * 16) + h * (NF0 * 16) + within;
-                const bool nvalid = pin && within < (h ? NF1 : NF0) * 16;
+                const int n = n0 + wcol * (NF * TS) + h * (NF0 * TS) + within;
+                const bool nvalid = pin && within < (h ? NF1 : NF0) * TS;
                 // rows past the packed weights fail the range check like the marker does: zeros
                 wbase[h][i] = nvalid ? ((unsigned)n * (unsigned)a.w_ld + kc * 8) * 2u : Y5_BUF_OOB;
             }
         }
         }
         // position of this thread's chunk in K-tile kt: 1 << tap (0 when the chunk lies past K or the K-tile past the
-        // last one) and the byte offset of (tap, channel) from tap (0, 0)
+        // last one) and the byte offset of (tap, channel) from tap (0, 0); with UNI both are the same for all lanes (the
+        // lane's K-chunk is then part of pbase)
         unsigned pbit = 0;
         int poff = 0;
         auto decode = [&](int kt) {
-            const unsigned k = (unsigned)kt * 64u + (unsigned)kc * 8u;
-            const unsigned tp = __umulhi(k, cin_mul) >> cin_shr;  // k / Cin (Cin >= 8: never the divisor-1 case)
-            const int c = (int)(k - tp * argCin);
-            const int r = (int)(tp * 11u) >> 5, q = (int)tp - 3 * r;
-            poff = ((r * argW + q) * arg_xld + c) * 2;
-            pbit = (kt < nk && k < argK) ? 1u << (tp & 15u) : 0u;  // k < K: tap < 9
+            if constexpr (UNI) {
+                const unsigned k = (unsigned)kt * 64u;
+                const unsigned tp = (unsigned)(((unsigned long long)k * cin_mul) >> 32) >> cin_shr;
+                const int c = (int)(k - tp * argCin);
+                const int r = (int)(tp * 11u) >> 5, q = (int)tp - 3 * r;
+                poff = ((r * argW + q) * arg_xld + c) * 2;
+                pbit = kt < nk ? 1u << (tp & 15u) : 0u;
+            } else {
+                const unsigned k = (unsigned)kt * 64u + (unsigned)kc * 8u;
+                const unsigned tp = __umulhi(k, cin_mul) >> cin_shr;  // k / Cin (Cin >= 8: never the divisor-1 case)
+                const int c = (int)(k - tp * argCin);
+                const int r = (int)(tp * 11u) >> 5, q = (int)tp - 3 * r;
+                poff = ((r * argW + q) * arg_xld + c) * 2;
+                pbit = (kt < nk && k < argK) ? 1u << (tp & 15u) : 0u;  // k < K: tap < 9
+            }
         };
         auto issue_p = [&](int h, int slot) {
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
                 const bool out = 8 * i + 7 >= Cfg::P_PIECES && wave + 8 * i >= Cfg::P_PIECES;  // only a slot's last pieces can lie past it
                 const unsigned dst = out ? (unsigned)Cfg::RING : (unsigned)(slot * P_SLOT + (wave + 8 * i) * 1024);
-                dma16_buf(xr, (pmask[i] & (pbit << (16 * h))) ? (unsigned)(pbase[h][i] + poff) : Y5_BUF_OOB, lds0 + dst);
+                dma16_buf_m0(xr, (pmask[i] & (pbit << (16 * h))) ? (unsigned)(pbase[h][i] + poff) : Y5_BUF_OOB, lds0 + dst);
             }
         };
         auto issue_w = [&](int h, int slot, int kt) {
@@ -218,19 +266,24 @@ __global__ __launch_bounds__(512, 2) void conv_ph_kernel(const ConvArgs a_unused
             for (int i = 0; i < NW; ++i) {
                 const bool out = 8 * i + 7 >= Cfg::W_PIECES && wave + 8 * i >= Cfg::W_PIECES;
                 const unsigned dst = out ? (unsigned)Cfg::RING : (unsigned)(W_RING + slot * W_SLOT + (wave + 8 * i) * 1024);
-                dma16_buf(wr, kt < nk ? wbase[h][i] + (unsigned)kt * 128u : Y5_BUF_OOB, lds0 + dst);
+                // past the last K-tile: + 2^30 puts a valid row offset (the packed weights span less than 2^30 bytes) past
+                // the descriptor's range and keeps the marker of an unused row there (no wrap)
+                dma16_buf_m0(wr, wbase[h][i] + (kt < nk ? (unsigned)kt * 128u : 0x40000000u), lds0 + dst);
             }
         };
 
-        ev8 pf[MF0][2], w0[NF0][2], w1[NF1 ? NF1 : 1][2];
-        f32x4 acc[MF][NF];
+        ev8 pf[MF0][KSN], wf[NF][KSN];
+        accv acc[MF][NF];
 #pragma unroll
         for (int i = 0; i < MF; ++i)
 #pragma unroll
-            for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NF; ++j)
+#pragma unroll
+                for (int e = 0; e < TS * TS / 64; ++e) acc[i][j][e] = 0.f;
 
-        // ---- prologue: K-tile 0 and three half-tiles of K-tile 1, in the order the loop continues.  (The staged tile of
-        // the previous round is no longer read: every wave passed the barrier behind its stores.)
+        // ---- prologue: K-tile 0 and P0, W0, W1 of K-tile 1, in the order the loop continues.  (The staged tile of the
+        // previous round is no longer read: every wave passed the barrier behind its stores.)
+        PH_STAMP(1)
         decode(0);
         issue_p(0, 0);
         issue_w(0, 0, 0);
@@ -239,60 +292,82 @@ __global__ __launch_bounds__(512, 2) void conv_ph_kernel(const ConvArgs a_unused
         decode(1);
         issue_p(0, 2);
         issue_w(0, 2, 1);
-        issue_p(1, 3);
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(VM) : "memory");  // K-tile 0 has landed for every wave
+        issue_w(1, 3, 1);
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NP + 2 * NW) : "memory");  // K-tile 0 has landed for every wave
         if (late) PH_BARRIER();
+        PH_STAMP(2)
 
+        // Two phases per K-tile, each one half of the wave's pixels by all of its channels.  Copies in issue order:
+        // ... [B of kt-1: P0, W0, W1 of kt+1] [A of kt: P1 of kt+1] [B of kt: P0, W0, W1 of kt+2] ...; every phase waits
+        // until all but the youngest VM copies are in, which retires what the NEXT phase reads; a slot is refilled no
+        // earlier than the phase after its last read, and every phase drains its reads before its first barrier.
+#ifdef Y5_STAMPS
+        unsigned long long sect[5] = {0, 0, 0, 0, 0}, sect_t = __builtin_amdgcn_s_memtime();
+#endif
         for (int kt = 0; kt < nk; ++kt) {
             const int s0 = (2 * kt) & 3, s1 = s0 + 1;
-            // phase 0: quadrant (P0, W0); refill W1 of K-tile kt+1
+            // phase A: pixels P0 x channels W0 | W1; P1 of K-tile kt+1 goes where P1 of kt-1 was
             PH_READ_P(s0, MF0)
-            PH_READ_W(w0, s0, NF0)
-            issue_w(1, (s1 + 2) & 3, kt + 1);
+            PH_READ_W(0, s0, NF0)
+            PH_READ_W(NF0, s1, NF1)
+            issue_p(1, (s1 + 2) & 3);
+            PH_SECT(0)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");
+            PH_SECT(1)
             PH_SYNC_READS();
-            PH_MMA(0, MF0, 0, NF0, w0)
+            PH_SECT(2)
+            PH_MMA(0, MF0)
+            PH_SECT(3)
             PH_BARRIER();
-            // phase 1: quadrant (P0, W1); refill P0 of K-tile kt+2 (the slot of this K-tile's P0, read in phase 0)
-            PH_READ_W(w1, s1, NF1)
+            PH_SECT(4)
+            // phase B: pixels P1, the weights still in registers; P0, W0, W1 of K-tile kt+2 go where this K-tile's were
+            PH_READ_P(s1, MF1)
             decode(kt + 2);
             issue_p(0, s0);
-            PH_SYNC_READS();
-            PH_MMA(0, MF0, NF0, NF1, w1)
-            PH_BARRIER();
-            // phase 2: quadrant (P1, W1); refill W0 of K-tile kt+2
-            PH_READ_P(s1, MF1)
             issue_w(0, s0, kt + 2);
-            PH_SYNC_READS();
-            PH_MMA(MF0, MF1, NF0, NF1, w1)
-            PH_BARRIER();
-            // phase 3: quadrant (P1, W0), W0 still in registers; refill P1 of K-tile kt+2; K-tile kt+1 must have landed
-            issue_p(1, s1);
+            issue_w(1, s1, kt + 2);  // (phase A of kt+1 issues P1 of kt+2 with this decode)
+            PH_SECT(0)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");
+            PH_SECT(1)
             PH_SYNC_READS();
-            PH_MMA(MF0, MF1, 0, NF0, w0)
+            PH_SECT(2)
+            PH_MMA(MF0, MF1)
+            PH_SECT(3)
             PH_BARRIER();
+            PH_SECT(4)
         }
+#ifdef Y5_STAMPS
+        if ((t == 0 || t == 256) && stamp_row < 65536)
+            for (int i = 0; i < 5; ++i) y5_ph_sect_buf[(2 * stamp_row + (t >> 8)) * 8 + i] = sect[i];
+#endif
         if (!late) PH_BARRIER();
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // the zero fills of the last K-tiles are in: the ring is free
+        PH_STAMP(3)
 
         // ---- epilogue: post-ops in registers -> 16-bit tile in LDS -> 16-byte stores (+ residual)
         PH_ARGS(a)
         const bool has_bias = a.bias != nullptr, has_scale = a.scale != nullptr;
         epi_store(prm, epi, t, BN);
         PH_SYNC_READS();
-        // accumulator (mi, nj), element e: pixel wm*MF*16 + mi*16 + lr, channel wn*NF*16 + nj*16 + lq*4 + e
+        // accumulator (mi, nj): pixel wm*MF*TS + mi*TS + lr; TS = 16: element e is channel wn*NF*16 + nj*16 + 4*lq + e;
+        // TS = 32: elements 4g .. 4g+3 are channels wn*NF*32 + nj*32 + 8g + 4*lq .. + 3
 #pragma unroll
         for (int nj = 0; nj < NF; ++nj) {
-            const int nl = wn * (NF * 16) + nj * 16 + lq * 4;
-            if (n0 + nl < a.Cout) {
 #pragma unroll
-                for (int mi = 0; mi < MF; ++mi) {
-                    const int ml = wm * (MF * 16) + mi * 16 + lr;
-                    *reinterpret_cast<ev4*>(smem + ml * EP + nl * 2) = post_op4_lds<ET>(acc[mi][nj], nl, prm, BN, has_bias, has_scale, a.slope);
+            for (int g = 0; g < TS / 16 * (TS / 16); ++g) {
+                const int nl = wn * (NF * TS) + nj * TS + (TS == 16 ? lq * 4 : 8 * g + 4 * lq);
+                if (n0 + nl < a.Cout) {
+#pragma unroll
+                    for (int mi = 0; mi < MF; ++mi) {
+                        const int ml = wm * (MF * TS) + mi * TS + lr;
+                        const f32x4 v = {acc[mi][nj][4 * g], acc[mi][nj][4 * g + 1], acc[mi][nj][4 * g + 2], acc[mi][nj][4 * g + 3]};
+                        *reinterpret_cast<ev4*>(smem + ml * EP + nl * 2) = post_op4_lds<ET>(v, nl, prm, BN, has_bias, has_scale, a.slope);
+                    }
                 }
             }
         }
         PH_SYNC_READS();
+        PH_STAMP(4)
         constexpr int CPR = BN / 8;  // 16-byte chunks per tile row
         ET* y = reinterpret_cast<ET*>(a.y);
         const ET* res = reinterpret_cast<const ET*>(a.res);
@@ -307,6 +382,8 @@ __global__ __launch_bounds__(512, 2) void conv_ph_kernel(const ConvArgs a_unused
             }
         }
         PH_SYNC_READS();  // every wave has read its part of the staged tile: the next round's DMAs may overwrite it
+        PH_STAMP(5)
+        PH_RSTAMP(7)
     }
 }
 #undef PH_READ_P
@@ -326,9 +403,10 @@ int ph_cu_count() {
     return n;
 }
 
-template <typename ET, int WM, int WN, int MF, int NF>
+template <typename ET, int WM, int WN, int MF, int NF, int TS>
 int launch_ph(const ConvArgs& a0, hipStream_t s) {
-    typedef PhCfg<WM, WN, MF, NF> Cfg;
+    const bool uni = a0.Cin % 64 == 0;
+    typedef PhCfg<WM, WN, MF, NF, TS> Cfg;
     ConvArgs a = a0;
     const long long tiles_m = (a.M + Cfg::BM - 1) / Cfg::BM;
     a.tiles_n = (a.Cout + Cfg::BN - 1) / Cfg::BN;
@@ -339,12 +417,16 @@ int launch_ph(const ConvArgs& a0, hipStream_t s) {
     static std::atomic<unsigned long long> attr_set{0};  // one bit per device: the attribute is per function and device
     const unsigned long long bit = 1ull << y5_current_device();
     if (!(attr_set.load() & bit)) {
-        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_ph_kernel<ET, WM, WN, MF, NF>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_ph_kernel<ET, WM, WN, MF, NF, TS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_ph_kernel<ET, WM, WN, MF, NF, TS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
         attr_set.fetch_or(bit);
     }
     const long long cus = ph_cu_count();
     const unsigned grid = (unsigned)(total < cus ? total : cus);  // one resident workgroup per compute unit, walking its tiles
-    hipLaunchKernelGGL((conv_ph_kernel<ET, WM, WN, MF, NF>), dim3(grid), dim3(512), Cfg::SMEM, s, a);
+    if (uni)
+        hipLaunchKernelGGL((conv_ph_kernel<ET, WM, WN, MF, NF, TS, true>), dim3(grid), dim3(512), Cfg::SMEM, s, a);
+    else
+        hipLaunchKernelGGL((conv_ph_kernel<ET, WM, WN, MF, NF, TS, false>), dim3(grid), dim3(512), Cfg::SMEM, s, a);
     Y5_LAUNCH_CHECK("conv_ph_kernel");
     return Y5_OK;
 }
@@ -353,18 +435,26 @@ struct PhVariant {
     int (*f16_launch)(const ConvArgs&, hipStream_t);
     int (*bf16_launch)(const ConvArgs&, hipStream_t);
 };
-#define Y5_PH(WM, WN, MF, NF) {&launch_ph<f16, WM, WN, MF, NF>, &launch_ph<bf16, WM, WN, MF, NF>}
+#define Y5_PH(WM, WN, MF, NF, TS) {&launch_ph<f16, WM, WN, MF, NF, TS>, &launch_ph<bf16, WM, WN, MF, NF, TS>}
 const PhVariant kPh[] = {
-    Y5_PH(2, 4, 8, 4),  // 256 pixels x 256 channels
-    Y5_PH(4, 2, 8, 4),  // 512 x 128
-    Y5_PH(2, 4, 7, 4),  // 224 x 256
-    Y5_PH(4, 2, 5, 4),  // 320 x 128
-    Y5_PH(4, 2, 5, 5),  // 320 x 160
-    Y5_PH(2, 4, 6, 5),  // 192 x 320
+    Y5_PH(2, 4, 8, 4, 16),  // 256 pixels x 256 channels
+    Y5_PH(4, 2, 8, 4, 16),  // 512 x 128
+    Y5_PH(2, 4, 7, 4, 16),  // 224 x 256
+    Y5_PH(4, 2, 5, 4, 16),  // 320 x 128
+    Y5_PH(4, 2, 5, 5, 16),  // 320 x 160
 };
 #undef Y5_PH
 
 }  // namespace
+
+#ifdef Y5_STAMPS
+extern "C" int y5_debug_sections_ph(unsigned long long* dst, int rows) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(y5_ph_sect_buf), (size_t)rows * 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
+extern "C" int y5_debug_stamps_ph(unsigned long long* dst, int rows) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(y5_ph_stamp_buf), (size_t)rows * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
+#endif
 
 int y5_conv_ph_count() { return (int)(sizeof(kPh) / sizeof(kPh[0])); }
 
@@ -372,7 +462,7 @@ int y5_conv_ph_count() { return (int)(sizeof(kPh) / sizeof(kPh[0])); }
 int y5_try_conv_ph(const y5_conv_desc& d, hipStream_t s, int which, int* rc) {
     if (which < 1 || which > y5_conv_ph_count()) return 0;
     if (d.ksize != 1 && d.ksize != 3) return 0;
-    if ((long long)d.w_rows * d.kpad * 2 >= 0x7fffffffLL) return 0;
+    if ((long long)d.w_rows * d.kpad * 2 >= 0x40000000LL) return 0;
     const long long img_span = (long long)d.h * d.w_in * d.x_ld * 2;
     if (img_span >= 0x7fffffffLL) return 0;
     // The loaders address x by 32-bit byte offsets: a batch whose input spans 2 GiB or more is convolved in slices of
