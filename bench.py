@@ -54,14 +54,14 @@ def reference_layer_work(model, x):
     return float(act * b + wts), float(flops * b)
 
 
-def build_model(name, device, head_gain=2.0):
+def build_model(name, device, head_gain=2.0, dtype=torch.float16):
     import util  # tests/util.py: seeded construction + BatchNorm calibration + head gain (synthetic weights)
     model = util.build_model(name, seed=0)
     util.calibrate(model, seed=1, size=640, head_gain=head_gain)
     fp32_fused = util.quiet(model.fuse).eval()
     import copy
     cpu_sd = {k: v.clone() for k, v in fp32_fused.state_dict().items()}
-    gpu_model = copy.deepcopy(fp32_fused).half().to(device).eval()
+    gpu_model = copy.deepcopy(fp32_fused).to(dtype).to(device).eval()
     return gpu_model, cpu_sd, float(max(fp32_fused.stride))
 
 
@@ -121,6 +121,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--serial-nms', action='store_true', help='NMS on the forward\'s own stream (no overlap with the next step)')
     ap.add_argument('--profile-passes', type=int, default=5)
+    ap.add_argument('--dtype', choices=('f16', 'bf16'), default='f16', help='element type of weights and activations (accumulation is fp32 either way)')
+    ap.add_argument('--fresh-outputs', action='store_true', help='allocate output tensors every step (the reference\'s behaviour) instead of reusing two sets')
     args = ap.parse_args()
 
     from yolo_amd import dist as ydist
@@ -144,10 +146,11 @@ def main():
 
     from yolo_amd import engine, nms as hip_nms
     import torch.distributed as dist
-    model, cpu_sd, _ = build_model(args.model, device, args.head_gain)
+    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float16
+    model, cpu_sd, _ = build_model(args.model, device, args.head_gain, dtype)
     strides = model.stride
     g = torch.Generator().manual_seed(1 + rank)
-    x = torch.rand(args.batch, 3, 640, 640, generator=g).half().to(device)
+    x = torch.rand(args.batch, 3, 640, 640, generator=g).to(dtype).to(device)
 
     local_out = [None]
 
@@ -156,13 +159,26 @@ def main():
     # still computes its own forward, decode, NMS (and exchange); fence() waits for both streams.
     side = None if args.serial_nms else torch.cuda.Stream(device)
 
+    # A serving loop allocates nothing per step: the launch plan writes into two sets of output tensors in turn and the
+    # NMS into two sets of its own (made once, below); step k's results stay valid until step k + 2 is issued.
+    post = None
+    if not args.fresh_outputs:
+        engine.set_output_ring(model, 2)
+        z, _ = model(x)
+        post = hip_nms.PaddedNms(z.shape[0], z.shape[1], z.shape[2], z.dtype, device, conf_thres=args.conf, iou_thres=args.iou, ring=2)
+
     def step(events=None):
+        if post is not None and side is not None:
+            post.wait_oldest()  # the forward about to be issued overwrites the prediction that NMS call read on the other stream
         if events is not None:
             events[0].record()
         z, _ = model(x)
         if events is not None:
             events[1].record()
-        det, count, kept, ncand = hip_nms.nms_padded(z, args.conf, args.iou, return_index=True, check_overflow=False, stream=side)
+        if post is not None:
+            det, count, kept, ncand = post(z, stream=side)
+        else:
+            det, count, kept, ncand = hip_nms.nms_padded(z, args.conf, args.iou, return_index=True, check_overflow=False, stream=side)
         if world > 1:
             with torch.cuda.stream(side):
                 local_out[0] = (det, count)
@@ -303,7 +319,7 @@ def main():
         lat = sorted(lat[5:])
         latency_b1_ms = lat[len(lat) // 2]
         top = sorted(conv, key=lambda a: -a['ms'])[:6]
-        roofline = {'kernel': 'convolution kernels (stem2 / csp1 / conv_c64 / conv_c128 / conv_s2c64 / conv_p1x1 / conv_p1x1_cat / conv_igemm / conv_lw / conv_lin3 / conv_ws1x1 / conv3x3_ws / detect_p): all %d launches of one forward'
+        roofline = {'kernel': 'convolution kernels (stem2 / csp1 / conv_c64 / conv_c128 / conv_s2c64 / conv_p1x1 / conv_p1x1_cat / conv_ph / conv_igemm / conv_lw / conv_lin3 / conv_ws1x1 / conv3x3_ws / detect_p): all %d launches of one forward'
                               % len(conv),
                     'bound': 'hbm' if hbm_bound else 'mfma',
                     'achieved': round(gbs if hbm_bound else tflops, 2), 'peak': PEAK_HBM_GBS if hbm_bound else PEAK_MFMA_TFLOPS,
@@ -320,13 +336,14 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_step, 4),
             'host_enqueue_ms_per_step': round(host_enqueue_ms, 4), 'forward_ms_in_loop': round(loop_forward_ms, 4),
             'latency_batch1_ms': round(latency_b1_ms, 4), 'rank_ms_per_step': {'min': round(min(rank_ms), 4), 'max': round(max(rank_ms), 4)},
-            'higher_is_better': True, 'scaling': 'strong' if args.global_batch else 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
-            'config': {'workload': '%s 640x640 fp16 batch %d per GPU, conf %g iou %g (test.py setting), random-init weights, '
-                                   'BatchNorm-calibrated, head gain %g' % (args.model, args.batch, args.conf, args.iou, args.head_gain),
+            'higher_is_better': True, 'scaling': 'strong' if args.global_batch else 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': '%s 640x640 %s batch %d per GPU, conf %g iou %g (test.py setting), random-init weights, '
+                                   'BatchNorm-calibrated, head gain %g' % (args.model, 'fp16' if args.dtype == 'f16' else 'bf16', args.batch, args.conf, args.iou, args.head_gain),
                        'global_batch': global_batch, 'parallelism': 'batch shard x%d, detection all_gather (%s)' % (world, dist.get_backend() if world > 1 else 'none'),
                        'gather_ms': None if gather_ms is None else round(gather_ms, 4),
                        'candidates_per_image': round(cand, 1), 'kept_per_image': round(kept, 1),
-                       'nms_stream': 'same stream as the forward' if side is None else 'second stream: NMS of step i beside the forward of step i+1'},
+                       'nms_stream': 'same stream as the forward' if side is None else 'second stream: NMS of step i beside the forward of step i+1',
+                       'outputs': 'fresh tensors every step' if post is None else 'two sets of output tensors reused in turn: no device allocation per step'},
             'roofline': roofline,
             'stages': {'note': 'forward_ms and nms_ms are timed on their own after the timed loop (one stream, nothing overlapped); plan_ms / conv_ms / decode_ms are per-launch event durations scaled to sum to forward_ms_in_loop',
                        'forward_ms': round(forward_ms, 4), 'plan_ms': round(plan_ms, 4), 'conv_ms': round(conv_ms, 4), 'decode_ms': round(dec_ms, 4), 'decode_kernels': 'head conv + decode fused' if det else 'decode',

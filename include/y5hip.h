@@ -341,7 +341,8 @@ int y5_sigmoid_f16(const void* x, void* y, int64_t n, int libm, y5_stream_t stre
  * original index first among equal scores); a visited box is kept unless an earlier KEPT box has
  * inter/(area_i + area_j - inter) > iou_thres, all in fp32 and compared in double.
  *
- * pred: (batch, n_rows, no) rows [cx, cy, w, h, obj, cls_0..]; dtype 0 = fp16, 1 = fp32.
+ * pred: (batch, n_rows, no) rows [cx, cy, w, h, obj, cls_0..]; pred_dtype 0 = fp16, 1 = fp32, 2 = bf16
+ * (every value is widened to fp32 before any arithmetic, as the reference does for fp16: utils/utils.py:580-581).
  * det: (batch, max_det, 6) fp32 rows [x1, y1, x2, y2, conf, cls], first count[b] rows valid, rest zero.
  * kept_index (optional): (batch, max_det) int32, anchor_row*nc + cls of each kept detection.
  * n_candidates (optional): (batch) int32, candidates that passed the confidence filter (uncapped).

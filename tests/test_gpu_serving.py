@@ -1,0 +1,129 @@
+"""The serving loop that allocates nothing: launch plans writing into a ring of output tensors (engine.set_output_ring)
+and NMS into caller-held tensors (nms_padded(out=...), PaddedNms), against the default path that returns fresh tensors."""
+import pytest
+import torch
+
+import util
+from yolo_amd import _lib, engine
+from yolo_amd.nms import PaddedNms, nms_buffers, nms_padded
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(dev):
+    model = util.build_model('yolov5s')
+    util.randomize_bn(model, 3)
+    model.eval()
+    util.quiet(model.fuse)
+    return model.half().to(dev)
+
+
+def _allocations(dev):
+    return torch.cuda.memory_stats(dev)['allocation.all.allocated']
+
+
+def test_ring_outputs_and_prepared_nms_equal_the_default_path(dev):
+    model = _model(dev)
+    g = torch.Generator().manual_seed(8)
+    batches = [torch.rand(4, 3, 128, 160, generator=g).half().to(dev) for _ in range(3)]
+    want = []
+    for x in batches:                      # default path: fresh tensors every call
+        z, xs = model(x)
+        want.append((z.clone(), [t.clone() for t in xs]) + tuple(t.clone() for t in nms_padded(z, 0.001, 0.6, return_index=True)))
+    engine.set_output_ring(model, 2)
+    B, N, no = want[0][0].shape
+    post = PaddedNms(B, N, no, torch.float16, dev, conf_thres=0.001, iou_thres=0.6, ring=2)
+    for x in batches:                      # warm: ring tensors exist, every lazy table of torch is built
+        post(model(x)[0])
+    torch.cuda.synchronize()
+    calls = engine.calls(model)
+    for step in range(10):
+        x = batches[step % 3]
+        z, xs = model(x)
+        det, count, kept, ncand = post(z)
+        if step >= 7:                      # results are read before their ring slot comes round again
+            zr, xr, dr, cr, kr, nr = want[step % 3]
+            assert torch.equal(z, zr) and all(torch.equal(a, b) for a, b in zip(xs, xr))
+            assert torch.equal(count, cr) and torch.equal(ncand, nr)
+            for b in range(B):
+                n = int(count[b])
+                assert torch.equal(det[b, :n], dr[b, :n]) and torch.equal(kept[b, :n], kr[b, :n])
+    torch.cuda.synchronize()
+    assert engine.calls(model) == calls + 10, 'every forward must have run on the HIP engine'
+
+
+def test_the_step_itself_leaves_the_allocation_counter_alone(dev):
+    model = _model(dev)
+    x = torch.rand(2, 3, 96, 96, generator=torch.Generator().manual_seed(1)).half().to(dev)
+    engine.set_output_ring(model, 2)
+    z, _ = model(x)
+    post = PaddedNms(*z.shape, torch.float16, dev, conf_thres=0.01, ring=2)
+    for _ in range(3):
+        post(model(x)[0])
+    torch.cuda.synchronize()
+    before = _allocations(dev)
+    for _ in range(10):
+        post(model(x)[0])
+    torch.cuda.synchronize()
+    assert _allocations(dev) == before
+    outs = {model(x)[0].data_ptr() for _ in range(6)}
+    assert len(outs) == 2, 'a ring of two sets of outputs'
+    engine.set_output_ring(model, 0)       # back to fresh tensors: two live results never share memory
+    a, b = model(x)[0], model(x)[0]
+    assert a.data_ptr() != b.data_ptr()
+    assert _allocations(dev) > before
+
+
+def test_nms_padded_into_caller_tensors_equals_the_allocating_call(dev):
+    g = torch.Generator().manual_seed(4)
+    pred = torch.rand(3, 2000, 85, generator=g)
+    pred[..., :4] *= 300
+    pred = pred.half().to(dev)
+    ref = nms_padded(pred, 0.3, 0.5, return_index=True)
+    out = nms_buffers(3, device=dev)
+    before = _allocations(dev)
+    got = nms_padded(pred, 0.3, 0.5, return_index=True, check_overflow=False, out=out)
+    assert _allocations(dev) == before
+    assert all(a is b for a, b in zip(got, out))
+    assert torch.equal(got[1], ref[1]) and torch.equal(got[3], ref[3])
+    for b in range(3):
+        n = int(ref[1][b])
+        assert n > 0 and torch.equal(got[0][b, :n], ref[0][b, :n]) and torch.equal(got[2][b, :n], ref[2][b, :n])
+    # class filter and agnostic mode through the prepared form
+    post = PaddedNms(3, 2000, 85, torch.float16, dev, conf_thres=0.3, iou_thres=0.5, classes=[0, 17, 42], agnostic=True)
+    ref = nms_padded(pred, 0.3, 0.5, classes=[0, 17, 42], agnostic=True, return_index=True)
+    got = post(pred)
+    assert torch.equal(got[1], ref[1])
+    for b in range(3):
+        n = int(ref[1][b])
+        assert torch.equal(got[0][b, :n], ref[0][b, :n]) and torch.equal(got[2][b, :n], ref[2][b, :n])
+
+
+def test_requests_the_caller_tensors_cannot_serve_are_refused(dev):
+    pred = torch.rand(2, 500, 85, generator=torch.Generator().manual_seed(2)).half().to(dev)
+    out = nms_buffers(2, device=dev)
+    with pytest.raises(_lib.Y5Error, match='more than max_candidates'):
+        nms_padded(pred, 0.001, 0.6, max_candidates=64, out=out)          # overflow: no silent retry with out=
+    with pytest.raises(ValueError):
+        nms_padded(pred, 0.3, 0.6, out=nms_buffers(3, device=dev))        # wrong batch
+    with pytest.raises(ValueError):
+        nms_padded(pred, 0.3, 0.6, out=out[:2])
+    big = torch.zeros(64, 8, 85, dtype=torch.float16, device=dev)
+    with pytest.raises(_lib.Y5Error, match='built-in scratch'):
+        nms_padded(big, 0.3, 0.6, max_candidates=65536, out=nms_buffers(64, device=dev))
+    post = PaddedNms(64, 8, 85, torch.float16, dev, max_candidates=65536)  # the prepared form brings its own workspace then
+    assert not post.builtin and int(post(big)[1].sum()) == 0
+    with pytest.raises(ValueError):
+        post(big[:32])
+
+
+def test_bf16_predictions_are_read_in_place_and_equal_their_fp32_copy(dev):
+    g = torch.Generator().manual_seed(6)
+    pred = torch.rand(2, 3000, 85, generator=g)
+    pred[..., :4] *= 400
+    pred = pred.bfloat16().to(dev)
+    ref = nms_padded(pred.float(), 0.2, 0.6, return_index=True)
+    got = nms_padded(pred, 0.2, 0.6, return_index=True)
+    assert all(torch.equal(a, b) for a, b in zip(got, ref)) and int(ref[1].min()) > 0
+    post = PaddedNms(2, 3000, 85, torch.bfloat16, dev, conf_thres=0.2, iou_thres=0.6)
+    assert all(torch.equal(a, b) for a, b in zip(post(pred), ref))

@@ -10,7 +10,8 @@ from yolo_amd import _lib
 dev = torch.device('cuda:0')
 lib = _lib.lib()
 NV = lib.y5_conv_num_variants()
-NPH = int(os.environ.get('NEW_VARIANTS', '12'))  # the pixel-resident (conv_pr.hip) and phased (conv_ph.hip) kernels: the last ids
+NPH = int(os.environ.get('NEW_VARIANTS', str(lib.y5_conv_num_variants_phased())))  # the phased kernels: the last ids
+RES = os.environ.get('RES', '0') == '1'           # give every layer a residual input (the Bottleneck shortcut)
 
 
 def setup(B, Ci, Co, H, W, k, s, seed=0):
@@ -37,7 +38,13 @@ def setup(B, Ci, Co, H, W, k, s, seed=0):
     d.ho, d.wo, d.cout, d.y_ld = Ho, Wo, cop, cop
     d.ksize, d.stride, d.pad, d.kpad, d.w_rows = k, s, k // 2, kpad, rows
     d.act, d.slope = _lib.ACT_LEAKY, 0.1
-    return d, (x, w, y, bias, wt)
+    res = None
+    if RES:
+        res = torch.zeros(B, Ho, Wo, cop, dtype=torch.float16)
+        res[..., :Co] = torch.randn(B, Ho, Wo, Co, generator=g).half()
+        res = res.to(dev)
+        d.res, d.res_ld = res.data_ptr(), cop
+    return d, (x, w, y, bias, wt, res)
 
 
 def check():
@@ -47,9 +54,11 @@ def check():
     st = _lib.current_stream()
     for shp in shapes:
         B, Ci, Co, H, W, k, s = shp
-        d, (x, w, y, bias, wt) = setup(*shp, seed=sum(shp))
+        d, (x, w, y, bias, wt, res) = setup(*shp, seed=sum(shp))
         xr = x[..., :Ci].permute(0, 3, 1, 2).float()
         ref = F.leaky_relu((F.conv2d(xr, wt.permute(0, 3, 1, 2).float().to(dev), None, s, k // 2) + bias[:Co].view(1, -1, 1, 1)).half().float(), 0.1).half()
+        if RES:
+            ref = ref + res[..., :Co].permute(0, 3, 1, 2)
         for v in range(NV - NPH + 1, NV + 1):
             y.fill_(float('nan'))
             d.variant = v

@@ -344,9 +344,25 @@ __global__ __launch_bounds__(512, 2) void conv_ph_kernel(const ConvArgs a_unused
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // the zero fills of the last K-tiles are in: the ring is free
         PH_STAMP(3)
 
-        // ---- epilogue: post-ops in registers -> 16-bit tile in LDS -> 16-byte stores (+ residual)
+        // ---- epilogue: post-ops in registers -> 16-bit tile in LDS -> 16-byte stores (+ residual).  The residual values
+        // are fetched first, into the registers the fragments have left, so that their latency lies under the post-ops.
         PH_ARGS(a)
         const bool has_bias = a.bias != nullptr, has_scale = a.scale != nullptr;
+        constexpr int CPR = BN / 8;                      // 16-byte chunks per tile row
+        constexpr int ITER = (BM * CPR + 511) / 512;     // chunks per thread
+        ET* y = reinterpret_cast<ET*>(a.y);
+        const ET* res = reinterpret_cast<const ET*>(a.res);
+        constexpr int NB = 4;                            // chunks per batch: one batch of residual values in flight
+        ev8 rv[NB];
+        auto fetch_res = [&](int i0) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int idx = t + (i0 + j) * 512;
+                const int row = idx / CPR, cc = idx - row * CPR;
+                const int m = m0 + row, n = n0 + cc * 8;
+                if (idx < BM * CPR && m < a.M && n < a.Cout) rv[j] = *reinterpret_cast<const ev8*>(res + (size_t)m * a.res_ld + n);
+            }
+        };
         epi_store(prm, epi, t, BN);
         PH_SYNC_READS();
         // accumulator (mi, nj): pixel wm*MF*TS + mi*TS + lr; TS = 16: element e is channel wn*NF*16 + nj*16 + 4*lq + e;
@@ -366,19 +382,25 @@ __global__ __launch_bounds__(512, 2) void conv_ph_kernel(const ConvArgs a_unused
                 }
             }
         }
+        if (res) fetch_res(0);
         PH_SYNC_READS();
         PH_STAMP(4)
-        constexpr int CPR = BN / 8;  // 16-byte chunks per tile row
-        ET* y = reinterpret_cast<ET*>(a.y);
-        const ET* res = reinterpret_cast<const ET*>(a.res);
-#pragma unroll 4
-        for (int idx = t; idx < BM * CPR; idx += 512) {
-            const int row = idx / CPR, cc = idx - row * CPR;
-            const int m = m0 + row, n = n0 + cc * 8;
-            if (m < a.M && n < a.Cout) {
-                ev8 v = *reinterpret_cast<const ev8*>(smem + row * EP + cc * 16);
-                if (res) v = Elem<ET>::add(v, *reinterpret_cast<const ev8*>(res + (size_t)m * a.res_ld + n));
-                *reinterpret_cast<ev8*>(y + (size_t)m * a.y_ld + n) = v;
+#pragma unroll 1
+        for (int i0 = 0; i0 < ITER; i0 += NB) {
+            ev8 cur[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) cur[j] = rv[j];
+            if (res && i0 + NB < ITER) fetch_res(i0 + NB);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int idx = t + (i0 + j) * 512;
+                const int row = idx / CPR, cc = idx - row * CPR;
+                const int m = m0 + row, n = n0 + cc * 8;
+                if (idx < BM * CPR && m < a.M && n < a.Cout) {
+                    ev8 v = *reinterpret_cast<const ev8*>(smem + row * EP + cc * 16);
+                    if (res) v = Elem<ET>::add(v, cur[j]);
+                    *reinterpret_cast<ev8*>(y + (size_t)m * a.y_ld + n) = v;
+                }
             }
         }
         PH_SYNC_READS();  // every wave has read its part of the staged tile: the next round's DMAs may overwrite it

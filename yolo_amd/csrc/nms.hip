@@ -41,6 +41,7 @@ __device__ __forceinline__ float score_from_bits(unsigned inv) {
 
 __device__ __forceinline__ float ldf(const f16* p) { return (float)*p; }
 __device__ __forceinline__ float ldf(const float* p) { return *p; }
+__device__ __forceinline__ float ldf(const bf16* p) { return (float)*p; }
 
 // ------------------------------------------------------------------------------------------
 // 1. candidates
@@ -655,7 +656,7 @@ namespace {
 int nms_check(const y5_nms_desc* d) {
     Y5_REQUIRE(d, "nms: null descriptor");
     Y5_REQUIRE(d->pred && d->det && d->count, "nms: null pointer");
-    Y5_REQUIRE(d->pred_dtype == 0 || d->pred_dtype == 1, "nms: pred_dtype %d not in {0 fp16, 1 fp32}", d->pred_dtype);
+    Y5_REQUIRE(d->pred_dtype >= 0 && d->pred_dtype <= 2, "nms: pred_dtype %d not in {0 fp16, 1 fp32, 2 bf16}", d->pred_dtype);
     Y5_REQUIRE(d->batch > 0 && d->n_rows > 0 && d->no >= 6, "nms: bad shape (%d, %d, %d)", d->batch, d->n_rows, d->no);
     Y5_REQUIRE((long long)d->n_rows * (d->no - 5) < 0x7fffffffLL, "nms: rows*classes overflows the 32-bit candidate index");
     Y5_REQUIRE(d->max_det > 0 && d->max_det <= MAX_DET_CAP, "nms: max_det %d out of range 1..%d", d->max_det, MAX_DET_CAP);
@@ -673,17 +674,21 @@ int nms_run(const y5_nms_desc* d, void* workspace, hipStream_t s) {
 
     Y5_HIP(hipMemsetAsync(counters, 0, counters_bytes, s));
     const dim3 cgrid((unsigned)((d->n_rows + CAND_ROWS - 1) / CAND_ROWS), (unsigned)d->batch);
-    const size_t tile_bytes = ((size_t)CAND_ROWS * d->no * (d->pred_dtype == 0 ? 2 : 4) + 15) / 16 * 16;
+    const size_t tile_bytes = ((size_t)CAND_ROWS * d->no * (d->pred_dtype == 1 ? 4 : 2) + 15) / 16 * 16;
     Y5_REQUIRE(tile_bytes <= 150 * 1024, "nms: %d values per row do not fit the staging tile", d->no);
     static std::atomic<unsigned long long> cand_attr{0};  // one bit per device: the attribute is per function and device
     const unsigned long long cand_attr_bit = 1ull << y5_current_device();
     if (!(cand_attr.load() & cand_attr_bit)) {
         Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_candidates_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_candidates_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_candidates_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         cand_attr.fetch_or(cand_attr_bit);
     }
     if (d->pred_dtype == 0)
         hipLaunchKernelGGL(nms_candidates_kernel<f16>, cgrid, dim3(CAND_THREADS), tile_bytes, s, static_cast<const f16*>(d->pred),
+                           d->n_rows, d->no, d->conf_thres, d->class_keep, keys, cap_pow2, counters);
+    else if (d->pred_dtype == 2)
+        hipLaunchKernelGGL(nms_candidates_kernel<bf16>, cgrid, dim3(CAND_THREADS), tile_bytes, s, static_cast<const bf16*>(d->pred),
                            d->n_rows, d->no, d->conf_thres, d->class_keep, keys, cap_pow2, counters);
     else
         hipLaunchKernelGGL(nms_candidates_kernel<float>, cgrid, dim3(CAND_THREADS), tile_bytes, s, static_cast<const float*>(d->pred),
@@ -699,6 +704,8 @@ int nms_run(const y5_nms_desc* d, void* workspace, hipStream_t s) {
     a.n_rows = d->n_rows; a.no = d->no; a.cap = d->max_candidates; a.cap_pow2 = cap_pow2; a.max_det = d->max_det; a.agnostic = d->agnostic;
     if (d->pred_dtype == 0)
         hipLaunchKernelGGL((nms_select_kernel<f16, false>), dim3((unsigned)d->batch), dim3(SEL_THREADS), 0, s, a);
+    else if (d->pred_dtype == 2)
+        hipLaunchKernelGGL((nms_select_kernel<bf16, false>), dim3((unsigned)d->batch), dim3(SEL_THREADS), 0, s, a);
     else
         hipLaunchKernelGGL((nms_select_kernel<float, false>), dim3((unsigned)d->batch), dim3(SEL_THREADS), 0, s, a);
     Y5_LAUNCH_CHECK("nms_select_kernel");

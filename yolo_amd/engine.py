@@ -268,6 +268,17 @@ def _engine_of(model):
     return eng
 
 
+def set_output_ring(model, n):
+    """Serving loops: let every launch plan of `model` write its outputs (z and the raw head maps x_i) into n sets of
+    tensors allocated once and used in turn, so that a forward allocates nothing.  The tensors a forward returns are
+    then overwritten by the n-th forward after it: consume (or copy) them before that.  n = 0 restores fresh output
+    tensors per forward, the default (environment: Y5_OUTPUT_RING)."""
+    eng = _engine_of(model)
+    eng.output_ring = max(0, int(n))
+    for plan in eng.plans.values():
+        plan.set_ring(eng.output_ring)
+
+
 def engine_of(model):
     """The Engine that has served `model` so far, or None (tests and benchmarks read its counters)."""
     return _ENGINES.get(model)
@@ -373,6 +384,7 @@ class Plan:
         self.keep = []          # tensors the plan's device pointers refer to
         self.labels = []        # one human-readable label per op
         self._defer = None      # list collecting (label, descriptor, input) instead of recording, see _emit_conv
+        self._ring, self._turn = [], 0  # sets of output tensors handed out in turn (set_ring); empty: fresh tensors per run
         self.homes = {}
         handle = C.c_void_p()
         _lib.check(self.lib.y5_plan_create(C.byref(handle)))
@@ -1349,10 +1361,25 @@ class Plan:
             arr[2 + i] = t.data_ptr()
         return arr
 
+    def set_ring(self, n):
+        """Keep n sets of output tensors (z and every x_i) and hand them out in turn instead of allocating per forward;
+        n = 0 goes back to fresh tensors.  With a ring the results of forward k are overwritten by forward k + n."""
+        self._ring, self._turn = [], 0
+        for _ in range(max(0, int(n))):
+            z = torch.empty(self.z_shape, dtype=self.dtype, device=self.device)
+            xs = [torch.empty(s, dtype=self.dtype, device=self.device) for s in self.x_shapes]
+            self._ring.append((z, xs, self._ext(z, z, xs)))
+
     def run(self, x):
-        z = torch.empty(self.z_shape, dtype=self.dtype, device=self.device)
-        xs = [torch.empty(s, dtype=self.dtype, device=self.device) for s in self.x_shapes]
-        ext = self._ext(x, z, xs)
+        ring = self._ring
+        if ring:
+            z, xs, ext = ring[self._turn]
+            self._turn = (self._turn + 1) % len(ring)
+            ext[0] = x.data_ptr()
+        else:
+            z = torch.empty(self.z_shape, dtype=self.dtype, device=self.device)
+            xs = [torch.empty(s, dtype=self.dtype, device=self.device) for s in self.x_shapes]
+            ext = self._ext(x, z, xs)
         _lib.check(self.lib.y5_plan_run(self.handle, ext, len(ext), _lib.current_stream()))
         return z, xs
 
@@ -1402,6 +1429,7 @@ class Engine:
         self.unsupported = None   # (signature, reason) of the last failed lowering
         self.calls = 0            # forwards executed by HIP kernels (read by tests)
         self.walks = 0            # full walks of the model (tests: the steady state does none)
+        self.output_ring = int(os.environ.get('Y5_OUTPUT_RING', '0'))  # sets of output tensors each plan reuses; 0 = fresh tensors
         self._state = None
 
     @property
@@ -1467,6 +1495,7 @@ class Engine:
             except Unsupported as e:
                 self.unsupported = ((sig, key), str(e))
                 return None
+            plan.set_ring(self.output_ring)
             self.plans[key] = plan
             while len(self.plans) > max(1, MAX_PLANS):  # a rectangular-batch loader feeds many shapes: bound the buffers held
                 _, old = self.plans.popitem(last=False)
