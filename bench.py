@@ -133,6 +133,7 @@ def main():
     if world != args.gpus:
         raise SystemExit('bench: --gpus %d but WORLD_SIZE is %d' % (args.gpus, world))
     device = torch.device('cuda', local % max(1, torch.cuda.device_count()))  # ranks share devices only in a rehearsal
+    pinned = ydist.pin_cpus(local, int(os.environ.get('LOCAL_WORLD_SIZE', world)))
     torch.cuda.set_device(device)
     torch.set_grad_enabled(False)
     if args.global_batch:
@@ -161,6 +162,8 @@ def main():
 
     # A serving loop allocates nothing per step: the launch plan writes into two sets of output tensors in turn and the
     # NMS into two sets of its own (made once, below); step k's results stay valid until step k + 2 is issued.
+    # kernel variants are timed by rank 0 only; the other ranks replay its choices
+    tuned_elsewhere = ydist.tune_once(lambda: model(x))
     post = None
     if not args.fresh_outputs:
         engine.set_output_ring(model, 2)
@@ -341,6 +344,8 @@ def main():
                                    'BatchNorm-calibrated, head gain %g' % (args.model, 'fp16' if args.dtype == 'f16' else 'bf16', args.batch, args.conf, args.iou, args.head_gain),
                        'global_batch': global_batch, 'parallelism': 'batch shard x%d, detection all_gather (%s)' % (world, dist.get_backend() if world > 1 else 'none'),
                        'gather_ms': None if gather_ms is None else round(gather_ms, 4),
+                       'tuning': 'kernel variants timed by this process' if world == 1 else 'kernel variants timed by rank 0, broadcast to the other ranks',
+                       'cpus_per_rank': None if pinned is None else len(pinned),
                        'candidates_per_image': round(cand, 1), 'kept_per_image': round(kept, 1),
                        'nms_stream': 'same stream as the forward' if side is None else 'second stream: NMS of step i beside the forward of step i+1',
                        'outputs': 'fresh tensors every step' if post is None else 'two sets of output tensors reused in turn: no device allocation per step'},

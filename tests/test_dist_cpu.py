@@ -103,3 +103,96 @@ def test_launch_ranks_reports_a_failing_rank_and_stops_the_rest(tmp_path):
     t0 = time.time()
     assert ydist.launch_ranks([sys.executable, str(script)], 2, timeout=120) == 3
     assert time.time() - t0 < 30
+
+
+def _forward_nms(model, x):
+    with torch.no_grad():
+        z, _ = model(x)
+    return _pad(yu.non_max_suppression(z, 0.05, 0.6))
+
+
+def _sharded_model_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    r, w, _ = ydist.init_from_env(backend='gloo')
+    model = util.build_model('yolov5s', seed=0)
+    util.calibrate(model, seed=1, size=64, head_gain=2.0)
+    model.eval()
+    x = torch.rand(6, 3, 64, 64, generator=torch.Generator().manual_seed(3))   # the global batch, the same on every rank
+    lo, hi = ydist.shard_bounds(x.shape[0], r, w)
+    det_all, cnt_all = ydist.gather_detections(*_forward_nms(model, x[lo:hi]))
+    if r == 0:
+        det_one, cnt_one = _forward_nms(model, x)
+        q.put((det_all.numpy(), cnt_all.numpy(), det_one.numpy(), cnt_one.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_global_batch_sharded_over_two_ranks_detects_what_one_process_detects():
+    """bench.py --global-batch: every rank runs forward + NMS on its contiguous slice of the batch and the gather puts
+    the slices back in image order; the result is the single-process result of the whole batch (same counts, boxes equal
+    up to the CPU convolution's batch-size-dependent summation order)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_model_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    det_all, cnt_all, det_one, cnt_one = q.get()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert det_all.shape == det_one.shape == (6, 300, 6)
+    assert np.array_equal(cnt_all, cnt_one) and int(cnt_one.min()) > 0
+    assert np.allclose(det_all, det_one, rtol=1e-4, atol=1e-3)
+
+
+def _tune_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from yolo_amd import engine
+    ydist.init_from_env(backend='gloo')
+    key = (32, 20, 20, 512, 512, 512, 512, 3, 1, False, True, False, 0)
+    seen = []
+
+    def warm():  # stands for the forwards whose plans time every variant: rank 0 "tunes", the others must find its choice
+        seen.append(dict(engine._TUNED))
+        if rank == 0:
+            engine._TUNED[key], engine._TUNED_MS[key] = 96, 0.098
+    taken = ydist.tune_once(warm)
+    q.put((rank, taken, seen[0].get(key), key in engine._REPLAYED))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tune_once_hands_rank_zeros_choices_to_the_other_ranks():
+    ctx = mp.get_context('spawn')
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tune_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict((r, rest) for r, *rest in (q.get(), q.get()))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got[0] == [0, None, False]     # rank 0 started from nothing and timed for itself
+    assert got[1] == [1, 96, True]        # rank 1 ran warm() with rank 0's choice in place, marked for a trial launch
+
+
+def test_pin_cpus_gives_ranks_disjoint_shares(monkeypatch):
+    have = sorted(os.sched_getaffinity(0))
+    if len(have) < 2:
+        import pytest
+        pytest.skip('one CPU')
+    try:
+        a = ydist.pin_cpus(0, 2)
+        assert a == set(have[:len(have) // 2]) and os.sched_getaffinity(0) == a
+        os.sched_setaffinity(0, have)
+        b = ydist.pin_cpus(1, 2)
+        assert b == set(have[len(have) // 2:2 * (len(have) // 2)]) and not (a & b)
+        os.sched_setaffinity(0, have)
+        monkeypatch.setenv('Y5_PIN_CPUS', '0')
+        assert ydist.pin_cpus(0, 2) is None and sorted(os.sched_getaffinity(0)) == have
+        assert ydist.pin_cpus(0, 1) is None
+    finally:
+        os.sched_setaffinity(0, have)

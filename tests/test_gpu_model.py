@@ -341,7 +341,9 @@ def test_plan_is_rebuilt_after_model_changes_and_not_otherwise(dev):
     model.float().half()                                    # new storage for every tensor
     z4, _ = model(x)
     assert torch.equal(z4, z3)
-    util.quiet(model.fuse)
+    model.float()
+    util.quiet(model.fuse)                                  # folds in fp32, as the reference does before .half()
+    model.half()
     z5, _ = model(x)
     agree(z5, torch_walk(), 0.80)
     conv = model.model[-1].m[0]

@@ -51,6 +51,23 @@ def main():
         ('nms_padded (same stream)', wall(lambda: hip_nms.nms_padded(z, 0.001, 0.65, check_overflow=False), n)),
         ('nms_padded (side stream)', wall(lambda: hip_nms.nms_padded(z, 0.001, 0.65, check_overflow=False, stream=side), n)),
     ]
+    engine.set_output_ring(model, 2)
+    post = hip_nms.PaddedNms(z.shape[0], z.shape[1], z.shape[2], z.dtype, dev, conf_thres=0.001, iou_thres=0.65, ring=2)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def step():
+        post.wait_oldest()
+        e0.record()
+        zz, _ = model(x)
+        e1.record()
+        post(zz, stream=side)
+    rows += [
+        ('model(x), outputs from a ring of two', wall(lambda: model(x), n)),
+        ('PaddedNms (same stream)', wall(lambda: post(z), n)),
+        ('PaddedNms (side stream)', wall(lambda: post(z, stream=side), n)),
+        ('two event records', wall(lambda: (e0.record(), e1.record()), n)),
+        ('whole step as bench.py issues it', wall(step, n)),
+    ]
     for name, ms in rows:
         print('%-55s %.4f ms' % (name, ms))
 

@@ -33,6 +33,48 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def pin_cpus(local_rank, local_world):
+    """Give this rank its own contiguous share of the CPUs the process may run on (sched_setaffinity): eight Python
+    launch threads then do not migrate across sockets or share cores.  Contiguous shares follow the usual numbering
+    (sockets in order, GPUs 0..n/2-1 on the first socket).  Y5_PIN_CPUS=0 leaves the affinity alone.  Returns the
+    CPU set taken, or None when nothing was changed."""
+    if os.environ.get('Y5_PIN_CPUS', '1') == '0' or local_world <= 1 or not hasattr(os, 'sched_setaffinity'):
+        return None
+    cpus = sorted(os.sched_getaffinity(0))
+    share = len(cpus) // local_world
+    if share < 1:
+        return None
+    mine = set(cpus[local_rank * share:(local_rank + 1) * share])
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    return mine
+
+
+def tune_once(warm, group=None):
+    """Kernel-variant choices made once for the job: rank 0 runs warm() (the forwards whose launch plans time every
+    variant), sends its choices to the other ranks, and those run warm() replaying them without timing anything.  All
+    ranks then launch the same kernels (the per-step time is the MAX over ranks, so one rank's unlucky choice is the
+    job's) and start-up costs one tuning pass, not `world` concurrent ones.  Ranks whose library build or device differs
+    from rank 0's ignore the choices and tune for themselves.  Returns the number of choices this rank took over."""
+    from yolo_amd import engine
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        warm()
+        return 0
+    rank = dist.get_rank(group)
+    payload = [None]
+    if rank == 0:
+        warm()
+        payload[0] = engine.export_tuning()
+    dist.broadcast_object_list(payload, src=0, group=group)
+    taken = 0
+    if rank != 0:
+        taken = engine.import_tuning(payload[0])
+        warm()
+    return taken
+
+
 def shard_bounds(total, rank, world):
     """Contiguous slice [lo, hi) of a batch of `total` images owned by `rank` (sizes differ by at most one)."""
     base, extra = divmod(total, world)

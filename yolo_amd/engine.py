@@ -17,6 +17,7 @@ import collections
 import ctypes as C
 import json
 import math
+import operator
 import os
 import weakref
 
@@ -28,6 +29,8 @@ from yolo_amd import _lib
 from yolo_amd.utils.torch_utils import bn_affine
 
 _DISABLED = [0]
+_VERSION_OF = operator.attrgetter('_version')  # the two per-tensor reads of Engine.state(), as C callables for map()
+_ADDRESS_OF = torch.Tensor.data_ptr
 def _fastest(candidates, launch):
     """The fastest of `candidates` (variant ids) and its milliseconds per launch.  launch(v) issues one launch of variant v
     on the current stream and returns 0, or non-zero when the variant does not apply to the shape.  Every applicable
@@ -91,12 +94,19 @@ def _fingerprint():
                          lib.y5_conv_cat2_num_variants(), lib.y5_detect_num_variants()]}
 
 
-def load_tune_cache(path):
-    """Read variant choices written by save_tune_cache: later plans of those shapes take them without timing anything
-    (each is launched once before it is recorded; one the library rejects is timed afresh).  Returns the number of
-    choices taken: 0 when the file was written under another library build or device architecture."""
-    with open(path) as f:
-        data = json.load(f)
+def export_tuning():
+    """Every variant choice of this process as plain data: {json(shape key): [variant, ms]} plus the library fingerprint
+    under '__fingerprint__' (what save_tune_cache writes, what ranks send each other)."""
+    data = {_cache_key(list(k)): [v, _TUNED_MS.get(k, 0.0)] for k, v in _TUNED.items()}
+    data['__fingerprint__'] = _fingerprint()
+    return data
+
+
+def import_tuning(data):
+    """Take the choices of export_tuning(): later plans of those shapes use them without timing anything (each is
+    launched once before it is recorded; one the library rejects is timed afresh).  Returns the number of choices
+    taken: 0 when they were made under another library build or device architecture."""
+    data = dict(data)
     if data.pop('__fingerprint__', None) != _fingerprint():
         return 0
     for k, (variant, ms) in data.items():
@@ -106,10 +116,15 @@ def load_tune_cache(path):
     return len(data)
 
 
+def load_tune_cache(path):
+    """import_tuning() of a file written by save_tune_cache."""
+    with open(path) as f:
+        return import_tuning(json.load(f))
+
+
 def save_tune_cache(path):
-    """Write every variant choice of this process (shape key -> [variant, ms]) as JSON, with the library fingerprint."""
-    data = {_cache_key(list(k)): [v, _TUNED_MS.get(k, 0.0)] for k, v in _TUNED.items()}
-    data['__fingerprint__'] = _fingerprint()
+    """Write export_tuning() as JSON."""
+    data = export_tuning()
     tmp = '%s.%d.tmp' % (path, os.getpid())
     with open(tmp, 'w') as f:
         json.dump(data, f, indent=0, sort_keys=True)
@@ -1469,7 +1484,7 @@ class Engine:
             ts = st.tensors
             stride = getattr(self.model.model[-1], 'stride', None)
             if (stride is st.stride and (st.stride_version is None or stride._version == st.stride_version)
-                    and [t._version for t in ts] == st.versions and [t.data_ptr() for t in ts] == st.ptrs):
+                    and list(map(_VERSION_OF, ts)) == st.versions and list(map(_ADDRESS_OF, ts)) == st.ptrs):
                 return st
         st = self._state = self._walk()
         if st.signature != self.signature:
