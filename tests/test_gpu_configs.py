@@ -81,13 +81,14 @@ def _check_config(dev, cfg, batch, pruned=False, calibrated=False, nms=False, ro
     assert bool(torch.isfinite(z.float()).all())
     # the oracle on a slice of the batch
     pick = sorted({0, batch - 1}) if oracle_images is None else list(oracle_images)
-    zr, xr = _oracle(cfg, model, x[pick])
-    if calibrated:
-        agree_calibrated(model, x[pick], [a[pick] for a in xs], xr)
-    else:
-        for a, b in zip(xs, xr):
-            agree(a[pick], b, 0.60)
-        agree(z[pick], zr, 0.90)
+    if pick:
+        zr, xr = _oracle(cfg, model, x[pick])
+        if calibrated:
+            agree_calibrated(model, x[pick], [a[pick] for a in xs], xr)
+        else:
+            for a, b in zip(xs, xr):
+                agree(a[pick], b, 0.60)
+            agree(z[pick], zr, 0.90)
     # every slot of the batch computes the same function
     if batch > 1:
         z2, xs2 = model(torch.roll(x, roll, 0))
@@ -131,11 +132,13 @@ def test_config3_yolov5m_l_640(dev, cfg):
 @pytest.mark.parametrize('cfg,batch', [('yolov5m', 64), ('yolov5l', 64), ('yolov5x', 128)])
 def test_config3_and_4_at_the_batch_sizes_the_throughput_figures_are_quoted_on(dev, cfg, batch):
     """The larger graphs at the batch the roofline study and the benchmark run them at (other tile counts, other variant
-    choices and persistent-kernel schedules than at batch 8): the oracle on the last image, then the whole batch through
-    the two properties that need no oracle - a rolled batch gives the rolled outputs bit for bit, and the NMS stage
-    equals the C oracle on every image of the predictions the engine produced (calibrated synthetic model: thousands
-    of candidates per image)."""
-    assert _check_config(dev, cfg, batch, calibrated=True, nms=True, roll=5, oracle_images=[batch - 1]) > 2000
+    choices and persistent-kernel schedules than at batch 8).  On the model with randomised BatchNorm statistics: the
+    oracle on the last image at the whole-graph tolerance, and a rolled batch gives the rolled outputs bit for bit.  On
+    the calibrated synthetic model (thousands of candidates per image; its unit-gain layers carry rounding differences
+    to the head, so the oracle comparison is the other model's job): roll invariance again and the NMS stage equal to the
+    C oracle on every image of the predictions the engine produced."""
+    _check_config(dev, cfg, batch, roll=5, oracle_images=[batch - 1])
+    assert _check_config(dev, cfg, batch, calibrated=True, nms=True, roll=7, oracle_images=[]) > 2000
 
 
 def test_config4_yolov5x_batch32_640(dev):

@@ -62,7 +62,7 @@ def test_the_step_itself_leaves_the_allocation_counter_alone(dev):
         post(model(x)[0])
     torch.cuda.synchronize()
     before = _allocations(dev)
-    for _ in range(10):
+    for _ in range(20):
         post(model(x)[0])
     torch.cuda.synchronize()
     assert _allocations(dev) == before
