@@ -349,6 +349,12 @@ int y5_sigmoid_f16(const void* x, void* y, int64_t n, int libm, y5_stream_t stre
  * If n_candidates[b] > max_candidates the image was truncated to an arbitrary subset and the
  * caller must retry with a larger capacity.
  * ------------------------------------------------------------------------------------------ */
+#define Y5_NMS_AGNOSTIC 1 /* one class for the IoU test (the `agnostic` argument, utils/utils.py:625) */
+#define Y5_NMS_MERGE 2    /* the merge step after the selection (the `merge` argument, utils/utils.py:630-639): in an image with
+                           * 1 < n < 3000 candidates every kept box becomes the score-weighted mean of all candidates that
+                           * overlap it by more than iou_thres, and kept boxes no second candidate overlaps are dropped; count
+                           * and kept_index follow.  Sums in fp64, rounded once: equal to the reference's fp32 matrix product
+                           * up to its summation order (a few ulp) */
 typedef struct y5_nms_desc {
     const void* pred;
     const uint8_t* class_keep; /* [nc] 1 = class allowed, or NULL = all (the `classes` argument) */
@@ -362,7 +368,7 @@ typedef struct y5_nms_desc {
     float conf_thres;
     int32_t pred_dtype;
     int32_t batch, n_rows, no;
-    int32_t agnostic;
+    int32_t agnostic;       /* flags: Y5_NMS_AGNOSTIC | Y5_NMS_MERGE */
     int32_t max_candidates; /* per-image candidate capacity */
     int32_t max_det;        /* <= 1024; 300 in the reference */
 } y5_nms_desc;

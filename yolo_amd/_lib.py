@@ -13,6 +13,7 @@ Y5_MAX_ANCHORS = 8
 Y5_MAX_LEVELS = 4
 NMS_NOALLOC_BYTES = (16 << 20) + 4096  # Y5_NMS_NOALLOC_BYTES
 PLAN_SIDE, PLAN_JOIN = 1, 2
+NMS_AGNOSTIC, NMS_MERGE = 1, 2  # flags of y5_nms_desc.agnostic
 ACT_NONE, ACT_LEAKY = 0, 1
 F16, BF16 = 0, 1  # y5_conv_desc.dtype / y5_decode_desc.dtype
 IN_F16, IN_U8, IN_U8_HWC, IN_U8_HWC_BGR = 0, 1, 2, 3  # input layouts of y5_focus_conv_u8_hwc

@@ -471,6 +471,101 @@ __global__ __launch_bounds__(SEL_THREADS) void nms_select_kernel(const SelectArg
     if (threadIdx.x == 0) a.count[b] = kcount;
 }
 
+// ------------------------------------------------------------------------------------------
+// 3b. merge step (utils/utils.py:630-639), one workgroup per image, after the selection: for an image with
+// 1 < n < 3000 candidates every kept box becomes the score-weighted mean of ALL candidates whose class-offset box overlaps
+// it by more than the threshold (box_iou, utils/utils.py:355-377, fp32, compared in fp32), and kept boxes that no second
+// candidate overlaps are dropped ("redundant").  The reference forms the sums with a matrix product whose summation
+// order is unspecified; here every sum is accumulated in fp64 in candidate order and rounded once to fp32, then divided
+// in fp32 as the reference divides.
+// ------------------------------------------------------------------------------------------
+constexpr int MERGE_MAX_N = 3000;     // the reference merges only when n < 3E3
+constexpr int MERGE_THREADS = 512;
+constexpr int MERGE_WAVES = MERGE_THREADS / 64;
+struct MergeCand { Box ob; float off, score; };
+constexpr size_t MERGE_LDS_BYTES = (size_t)MERGE_MAX_N * sizeof(MergeCand) + (size_t)MAX_DET_CAP * (7 * sizeof(float) + sizeof(int));
+
+template <typename T>
+__global__ __launch_bounds__(MERGE_THREADS) void nms_merge_boxes_kernel(const SelectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char merge_smem[];
+    MergeCand* cand = reinterpret_cast<MergeCand*>(merge_smem);
+    float* rows = reinterpret_cast<float*>(cand + MERGE_MAX_N);   // [max_det][6] merged rows
+    int* rflat = reinterpret_cast<int*>(rows + MAX_DET_CAP * 6);   // their kept_index entries
+    int* alive = rflat + MAX_DET_CAP;                              // 1 = overlapped by a second candidate
+    __shared__ int newcount;
+
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nc = a.no - 5;
+    const int n = a.counters[b];
+    if (!(n > 1 && n < MERGE_MAX_N) || n > a.cap) return;
+    const int K = a.count[b];
+    const u64* keys = a.keys + (long long)b * a.cap_pow2;
+    for (int i = tid; i < n; i += MERGE_THREADS) {
+        const Cand c = load_candidate<T, false>(a, keys, b, i, n, nc);
+        cand[i].ob = c.ob;
+        cand[i].off = a.agnostic ? 0.f : __fmul_rn(c.cls, CLASS_OFFSET);
+        cand[i].score = c.score;
+    }
+    __syncthreads();
+    const float thr = (float)a.iou_thres;
+    float* det = a.det + (long long)b * a.max_det * 6;
+    for (int k = wave; k < K; k += MERGE_WAVES) {
+        const float* r = det + k * 6;
+        const float koff = a.agnostic ? 0.f : __fmul_rn(r[5], CLASS_OFFSET);
+        const Box kb = {__fadd_rn(r[0], koff), __fadd_rn(r[1], koff), __fadd_rn(r[2], koff), __fadd_rn(r[3], koff)};
+        const float karea = __fmul_rn(__fsub_rn(kb.x2, kb.x1), __fsub_rn(kb.y2, kb.y1));
+        double sw = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int hits = 0;
+        for (int j = lane; j < n; j += 64) {
+            const MergeCand c = cand[j];
+            const Box cb = {__fadd_rn(c.ob.x1, c.off), __fadd_rn(c.ob.y1, c.off), __fadd_rn(c.ob.x2, c.off), __fadd_rn(c.ob.y2, c.off)};
+            const float carea = __fmul_rn(__fsub_rn(cb.x2, cb.x1), __fsub_rn(cb.y2, cb.y1));
+            const float w = fmaxf(__fsub_rn(fminf(kb.x2, cb.x2), fmaxf(kb.x1, cb.x1)), 0.f);
+            const float h = fmaxf(__fsub_rn(fminf(kb.y2, cb.y2), fmaxf(kb.y1, cb.y1)), 0.f);
+            const float inter = __fmul_rn(w, h);
+            const float iou = __fdiv_rn(inter, __fsub_rn(__fadd_rn(karea, carea), inter));
+            if (iou > thr) {
+                ++hits;
+                const double wt = (double)c.score;
+                sw += wt; s0 += wt * c.ob.x1; s1 += wt * c.ob.y1; s2 += wt * c.ob.x2; s3 += wt * c.ob.y2;
+            }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            sw += __shfl_xor(sw, d); s0 += __shfl_xor(s0, d); s1 += __shfl_xor(s1, d); s2 += __shfl_xor(s2, d); s3 += __shfl_xor(s3, d);
+            hits += __shfl_xor(hits, d);
+        }
+        if (lane == 0) {
+            const float den = (float)sw;
+            float* o = rows + k * 6;
+            o[0] = __fdiv_rn((float)s0, den); o[1] = __fdiv_rn((float)s1, den); o[2] = __fdiv_rn((float)s2, den); o[3] = __fdiv_rn((float)s3, den);
+            o[4] = r[4]; o[5] = r[5];
+            rflat[k] = a.kept_index ? a.kept_index[(long long)b * a.max_det + k] : 0;
+            alive[k] = hits > 1;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {  // positions of the surviving rows, in order
+        int pos = 0;
+        for (int k = 0; k < K; ++k) {
+            const int keep = alive[k];
+            alive[k] = keep ? pos : -1;
+            pos += keep;
+        }
+        newcount = pos;
+    }
+    __syncthreads();
+    for (int k = tid; k < K; k += MERGE_THREADS) {
+        const int pos = alive[k];
+        if (pos < 0) continue;
+        float* o = det + pos * 6;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) o[e] = rows[k * 6 + e];
+        if (a.kept_index) a.kept_index[(long long)b * a.max_det + pos] = rflat[k];
+    }
+    if (tid == 0) a.count[b] = newcount;
+}
+
 // zero the unused tail of det rows so that padded outputs are deterministic
 __global__ __launch_bounds__(256) void nms_clear_tail_kernel(float* det, int* kept_index, const int* count, int max_det) {
     const int b = blockIdx.x;
@@ -701,7 +796,7 @@ int nms_run(const y5_nms_desc* d, void* workspace, hipStream_t s) {
     a.pred = d->pred; a.keys = keys; a.counters = counters;
     a.det = d->det; a.count = d->count; a.kept_index = d->kept_index; a.n_candidates = d->n_candidates; a.keep64 = nullptr;
     a.iou_thres = d->iou_thres;
-    a.n_rows = d->n_rows; a.no = d->no; a.cap = d->max_candidates; a.cap_pow2 = cap_pow2; a.max_det = d->max_det; a.agnostic = d->agnostic;
+    a.n_rows = d->n_rows; a.no = d->no; a.cap = d->max_candidates; a.cap_pow2 = cap_pow2; a.max_det = d->max_det; a.agnostic = d->agnostic & Y5_NMS_AGNOSTIC;
     if (d->pred_dtype == 0)
         hipLaunchKernelGGL((nms_select_kernel<f16, false>), dim3((unsigned)d->batch), dim3(SEL_THREADS), 0, s, a);
     else if (d->pred_dtype == 2)
@@ -709,6 +804,23 @@ int nms_run(const y5_nms_desc* d, void* workspace, hipStream_t s) {
     else
         hipLaunchKernelGGL((nms_select_kernel<float, false>), dim3((unsigned)d->batch), dim3(SEL_THREADS), 0, s, a);
     Y5_LAUNCH_CHECK("nms_select_kernel");
+    if (d->agnostic & Y5_NMS_MERGE) {
+        static std::atomic<unsigned long long> merge_attr{0};
+        const unsigned long long bit = 1ull << y5_current_device();
+        if (!(merge_attr.load() & bit)) {
+            Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_merge_boxes_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MERGE_LDS_BYTES));
+            Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_merge_boxes_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MERGE_LDS_BYTES));
+            Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_merge_boxes_kernel<bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MERGE_LDS_BYTES));
+            merge_attr.fetch_or(bit);
+        }
+        if (d->pred_dtype == 0)
+            hipLaunchKernelGGL(nms_merge_boxes_kernel<f16>, dim3((unsigned)d->batch), dim3(MERGE_THREADS), MERGE_LDS_BYTES, s, a);
+        else if (d->pred_dtype == 2)
+            hipLaunchKernelGGL(nms_merge_boxes_kernel<bf16>, dim3((unsigned)d->batch), dim3(MERGE_THREADS), MERGE_LDS_BYTES, s, a);
+        else
+            hipLaunchKernelGGL(nms_merge_boxes_kernel<float>, dim3((unsigned)d->batch), dim3(MERGE_THREADS), MERGE_LDS_BYTES, s, a);
+        Y5_LAUNCH_CHECK("nms_merge_boxes_kernel");
+    }
     hipLaunchKernelGGL(nms_clear_tail_kernel, dim3((unsigned)d->batch), dim3(256), 0, s, d->det, d->kept_index, d->count, d->max_det);
     Y5_LAUNCH_CHECK("nms_clear_tail_kernel");
     return Y5_OK;

@@ -51,7 +51,7 @@ def _fits_builtin(lib, B, cap):
 
 
 def nms_padded(prediction, conf_thres=0.1, iou_thres=0.6, classes=None, agnostic=False, max_det=MAX_DET,
-               max_candidates=None, return_index=False, check_overflow=True, stream=None, out=None):
+               max_candidates=None, return_index=False, check_overflow=True, stream=None, out=None, merge=False):
     """Run the batched pipeline on a (B, N, 5+nc) fp16/fp32 GPU tensor.
 
     Returns (det, count) or (det, count, kept_index, n_candidates): det (B, max_det, 6) fp32 rows
@@ -59,6 +59,10 @@ def nms_padded(prediction, conf_thres=0.1, iou_thres=0.6, classes=None, agnostic
     the per-image candidate totals are read back once and the call is repeated with a larger capacity
     when an image produced more candidates than max_candidates; pass check_overflow=False (and inspect
     n_candidates yourself) to stay asynchronous.
+
+    merge: the reference's merge step after the selection (utils/utils.py:630-639), per image with 1 < n < 3000
+    candidates: kept boxes become the score-weighted mean of the candidates overlapping them, kept boxes that no second
+    candidate overlaps are dropped (kept_index and count follow).
 
     out: the tensors of nms_buffers(B, max_det, device), written in place and returned; the call then allocates no
     device memory: counters and sort keys live in a scratch array inside the library (y5_nms_batched_noalloc), which
@@ -112,7 +116,7 @@ def nms_padded(prediction, conf_thres=0.1, iou_thres=0.6, classes=None, agnostic
             d.iou_thres, d.conf_thres = float(iou_thres), float(conf_thres)
             d.pred_dtype = _PRED_DTYPE[prediction.dtype]
             d.batch, d.n_rows, d.no = B, N, no
-            d.agnostic = 1 if agnostic else 0
+            d.agnostic = (_lib.NMS_AGNOSTIC if agnostic else 0) | (_lib.NMS_MERGE if merge else 0)
             d.max_candidates, d.max_det = cap, max_det
             _lib.check((lib.y5_nms_batched if out is None else lib.y5_nms_batched_noalloc)(C.byref(d), _lib.current_stream()))
             # the candidate totals are read back on the stream that computed them (inside this context the reduction
@@ -139,7 +143,7 @@ class PaddedNms:
     workspace allocated here."""
 
     def __init__(self, batch, n_rows, no, dtype=torch.float16, device='cuda', conf_thres=0.1, iou_thres=0.6, classes=None,
-                 agnostic=False, max_det=MAX_DET, max_candidates=None, ring=1):
+                 agnostic=False, max_det=MAX_DET, max_candidates=None, ring=1, merge=False):
         if dtype not in _PRED_DTYPE:
             raise ValueError('PaddedNms takes fp16, bf16 or fp32 predictions')
         lib = _lib.lib()
@@ -166,7 +170,7 @@ class PaddedNms:
             d.iou_thres, d.conf_thres = float(iou_thres), float(conf_thres)
             d.pred_dtype = _PRED_DTYPE[dtype]
             d.batch, d.n_rows, d.no = batch, n_rows, no
-            d.agnostic = 1 if agnostic else 0
+            d.agnostic = (_lib.NMS_AGNOSTIC if agnostic else 0) | (_lib.NMS_MERGE if merge else 0)
             d.max_candidates, d.max_det = cap, max_det
             self.sets.append((bufs, d, C.byref(d), torch.cuda.Event()))
         self.turn = 0

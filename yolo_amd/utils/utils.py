@@ -194,11 +194,7 @@ def non_max_suppression(prediction, conf_thres=0.1, iou_thres=0.6, merge=False, 
     """
     if prediction.is_cuda:
         from yolo_amd import nms as hip_nms
-        if merge:
-            # merge-NMS re-weights boxes over the whole candidate set: candidates are built with the
-            # reference's tensor ops on the device and the box NMS primitive runs as a HIP kernel.
-            return _nms_stage_list(prediction, conf_thres, iou_thres, True, classes, agnostic, hip_nms.nms)
-        det, count = hip_nms.nms_padded(prediction, conf_thres, iou_thres, classes=classes, agnostic=agnostic)
+        det, count = hip_nms.nms_padded(prediction, conf_thres, iou_thres, classes=classes, agnostic=agnostic, merge=merge)
         counts = count.tolist()  # the one device->host sync of the call: the list API needs the lengths
         return [det[b, :c].clone() if c > 0 else None for b, c in enumerate(counts)]
     return _nms_stage_list(prediction, conf_thres, iou_thres, merge, classes, agnostic, _greedy_nms_host)
