@@ -122,6 +122,7 @@ def main():
     ap.add_argument('--serial-nms', action='store_true', help='NMS on the forward\'s own stream (no overlap with the next step)')
     ap.add_argument('--profile-passes', type=int, default=5)
     ap.add_argument('--dtype', choices=('f16', 'bf16'), default='f16', help='element type of weights and activations (accumulation is fp32 either way)')
+    ap.add_argument('--graph', action='store_true', help='replay the forward as captured HIP graphs (one launch per forward): less host time per step, same device time')
     ap.add_argument('--fresh-outputs', action='store_true', help='allocate output tensors every step (the reference\'s behaviour) instead of reusing two sets')
     args = ap.parse_args()
 
@@ -164,10 +165,12 @@ def main():
     # NMS into two sets of its own (made once, below); step k's results stay valid until step k + 2 is issued.
     # kernel variants are timed by rank 0 only; the other ranks replay its choices
     tuned_elsewhere = ydist.tune_once(lambda: model(x))
-    post = None
+    post, graphed = None, None
     if not args.fresh_outputs:
         engine.set_output_ring(model, 2)
         z, _ = model(x)
+        if args.graph:
+            graphed = engine.GraphedForward(model, x, sets=2)
         post = hip_nms.PaddedNms(z.shape[0], z.shape[1], z.shape[2], z.dtype, device, conf_thres=args.conf, iou_thres=args.iou, ring=2)
 
     def step(events=None):
@@ -175,7 +178,7 @@ def main():
             post.wait_oldest()  # the forward about to be issued overwrites the prediction that NMS call read on the other stream
         if events is not None:
             events[0].record()
-        z, _ = model(x)
+        z, _ = model(x) if graphed is None else graphed()
         if events is not None:
             events[1].record()
         if post is not None:
@@ -348,7 +351,8 @@ def main():
                        'cpus_per_rank': None if pinned is None else len(pinned),
                        'candidates_per_image': round(cand, 1), 'kept_per_image': round(kept, 1),
                        'nms_stream': 'same stream as the forward' if side is None else 'second stream: NMS of step i beside the forward of step i+1',
-                       'outputs': 'fresh tensors every step' if post is None else 'two sets of output tensors reused in turn: no device allocation per step'},
+                       'outputs': 'fresh tensors every step' if post is None else 'two sets of output tensors reused in turn: no device allocation per step',
+                       'forward_issue': 'one launch per kernel' if graphed is None else 'captured HIP graphs, one launch per forward'},
             'roofline': roofline,
             'stages': {'note': 'forward_ms and nms_ms are timed on their own after the timed loop (one stream, nothing overlapped); plan_ms / conv_ms / decode_ms are per-launch event durations scaled to sum to forward_ms_in_loop',
                        'forward_ms': round(forward_ms, 4), 'plan_ms': round(plan_ms, 4), 'conv_ms': round(conv_ms, 4), 'decode_ms': round(dec_ms, 4), 'decode_kernels': 'head conv + decode fused' if det else 'decode',

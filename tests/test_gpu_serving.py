@@ -128,3 +128,25 @@ def test_bf16_predictions_are_read_in_place_and_equal_their_fp32_copy(dev):
     post = PaddedNms(2, 3000, 85, torch.bfloat16, dev, conf_thres=0.6, iou_thres=0.6)
     assert int(ref[3].max()) < 65536  # no image overflows the default capacity, which PaddedNms does not grow
     assert all(torch.equal(a, b) for a, b in zip(post(pred), ref))
+
+
+def test_graphed_forward_replays_the_plan_and_refuses_a_changed_model(dev):
+    model = _model(dev)
+    g = torch.Generator().manual_seed(9)
+    a, b = (torch.rand(2, 3, 96, 128, generator=g).half().to(dev) for _ in range(2))
+    za, zb = model(a)[0].clone(), model(b)[0].clone()
+    x = a.clone()
+    fwd = engine.GraphedForward(model, x, sets=2)
+    calls = engine.calls(model)
+    z1, xs1 = fwd()
+    x.copy_(b)
+    z2, _ = fwd()
+    assert z1.data_ptr() != z2.data_ptr() and torch.equal(z1, za) and torch.equal(z2, zb)
+    x.copy_(a)
+    z3, xs3 = fwd()
+    assert z3.data_ptr() == z1.data_ptr() and torch.equal(z3, za) and len(xs3) == 3
+    assert engine.calls(model) == calls + 3
+    with torch.no_grad():
+        model.model[0].conv.conv.weight.mul_(1.25)
+    with pytest.raises(_lib.Y5Error, match='capture it again'):
+        fwd()

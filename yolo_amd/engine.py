@@ -294,6 +294,55 @@ def set_output_ring(model, n):
         plan.set_ring(eng.output_ring)
 
 
+class GraphedForward:
+    """The forward of `model` on the input buffer `x`, captured once as HIP graphs (one per output set) and replayed:
+    one graph launch per forward instead of one launch per kernel, for loops where the host's time per step matters
+    (measured on yolov5s at batch 32: 0.07 ms of host time per forward instead of 0.16 - 0.25; the device time does not
+    improve, the kernels are long enough to hide their launches, and is 0 - 3 % longer).
+
+    `x` is the graph's input buffer: write every new batch INTO it (x.copy_(batch)) before calling.  A call returns
+    (z, [x_i]) like the model, in output set k mod `sets`; a set is overwritten `sets` calls later.  The graphs hold the
+    addresses of the weights: after any change to the model (another dtype, fuse(), load_state_dict, pruning) a call
+    raises Y5Error and the forward must be captured again."""
+
+    def __init__(self, model, x, sets=2):
+        eng = _engine_of(model)
+        self._model = weakref.ref(model)
+        self.x = x
+        set_output_ring(model, sets)
+        plan = _plan_if_eligible(model, x)
+        if plan is None:
+            raise _lib.Y5Error('GraphedForward: this model / input does not run on the HIP engine')
+        self.signature = eng.state().signature
+        self.plan = plan
+        with torch.cuda.device(x.device):
+            plan.run(x)  # everything lazy (tuning, function attributes) has happened before the capture
+            plan._turn = 0
+            cur = torch.cuda.current_stream(x.device)
+            side = torch.cuda.Stream(x.device)
+            side.wait_stream(cur)
+            self.graphs, self.outs = [], []
+            with torch.cuda.stream(side):
+                for _ in range(max(1, int(sets))):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=side):
+                        out = plan.run(x)
+                    self.graphs.append(g)
+                    self.outs.append(out)
+            cur.wait_stream(side)
+        self.turn = 0
+
+    def __call__(self):
+        eng = _ENGINES.get(self._model())
+        if eng is None or self.plan.handle is None or eng.state().signature != self.signature:
+            raise _lib.Y5Error('GraphedForward: the model changed since the capture; capture it again')
+        k = self.turn
+        self.turn = (k + 1) % len(self.graphs)
+        self.graphs[k].replay()
+        eng.calls += 1
+        return self.outs[k]
+
+
 def engine_of(model):
     """The Engine that has served `model` so far, or None (tests and benchmarks read its counters)."""
     return _ENGINES.get(model)
