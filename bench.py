@@ -122,6 +122,7 @@ def main():
     ap.add_argument('--serial-nms', action='store_true', help='NMS on the forward\'s own stream (no overlap with the next step)')
     ap.add_argument('--profile-passes', type=int, default=5)
     ap.add_argument('--dtype', choices=('f16', 'bf16'), default='f16', help='element type of weights and activations (accumulation is fp32 either way)')
+    ap.add_argument('--ops-json', default='', help='write the per-op list of the plan (label, kind, ms, FLOPs, minimum bytes) to this file')
     ap.add_argument('--graph', action='store_true', help='replay the forward as captured HIP graphs (one launch per forward): less host time per step, same device time')
     ap.add_argument('--fresh-outputs', action='store_true', help='allocate output tensors every step (the reference\'s behaviour) instead of reusing two sets')
     args = ap.parse_args()
@@ -274,6 +275,9 @@ def main():
         event_scale = loop_forward_ms / sum(a['ms'] for a in acc)
         for a in acc:
             a['ms'] *= event_scale
+        if args.ops_json:
+            with open(args.ops_json, 'w') as f:
+                json.dump({'model': args.model, 'batch': args.batch, 'dtype': args.dtype, 'ops': acc}, f, indent=1)
         det = [a for a in acc if a['kind'] == 'detect']  # Detect levels as one kernel each: head conv with the decode as its epilogue
         conv = [a for a in acc if a['kind'] in ('conv', 'focus_conv')] + det
         conv_ms = sum(a['ms'] for a in conv)

@@ -2,7 +2,7 @@
 each).  One forward = the dispatches between the last two launches of the plan's first kernel (the Focus kernel); one
 NMS call = those between the last two launches of its first kernel.  FETCH_SIZE is doubled: on gfx950 it tallies the
 128-byte requests of wide coalesced reads at 64 bytes (narrower loads, as in the Focus kernel, are then over-counted).
-usage: hbm_traffic.py FETCH_DIR WRITE_DIR OUT.json"""
+usage: hbm_traffic.py FETCH_DIR WRITE_DIR OUT.json [MODEL BATCH]"""
 import csv, glob, json, os, sys
 from collections import defaultdict
 
@@ -16,7 +16,7 @@ def one_step(root, counter):
                     rows.append((int(r['Dispatch_Id']), r['Kernel_Name'], float(r['Counter_Value'])))
     rows.sort()
     out = []
-    for first, keep in ((('focus_conv_kernel', 'stem2_kernel'), lambda n: 'nms_' not in n), (('nms_candidates_kernel',), lambda n: 'nms_' in n)):
+    for first, keep in ((('focus_conv_kernel', 'stem2_kernel', 'stem_conv_kernel'), lambda n: 'nms_' not in n), (('nms_candidates_kernel',), lambda n: 'nms_' in n)):
         marks = [i for i, r in enumerate(rows) if any(k in r[1] for k in first)]
         if len(marks) < 2:
             raise SystemExit('fewer than two launches of %s in %s' % ('/'.join(first), root))
@@ -28,7 +28,7 @@ def family(name):
     for key, fam in (('csp1_kernel', 'conv_csp'), ('detect_p_kernel', 'conv_detect'), ('stem2_kernel', 'conv_stem2')):
         if key in name:
             return fam
-    for key in ('focus_conv', 'conv_lw', 'conv_lin3', 'conv_c64', 'conv_c128', 'conv_p1x1', 'conv_s2c64', 'conv_s2c32', 'conv_igemm', 'conv_halo', 'conv_ws1x1', 'conv3x3_ws', 'detect_decode', 'nms_', 'maxpool', 'upsample', 'copy_channels'):
+    for key in ('focus_conv', 'conv_ph', 'conv_lw', 'conv_lin3', 'conv_c64', 'conv_c128', 'conv_p1x1', 'conv_s2c64', 'conv_s2c32', 'conv_igemm', 'conv_halo', 'conv_ws1x1', 'conv3x3_ws', 'detect_decode', 'nms_', 'maxpool', 'upsample', 'copy_channels'):
         if key in name:
             return key
     return 'other'
@@ -42,7 +42,9 @@ for _, name, v in fetch:
     per[family(name)][2] += 1
 for _, name, v in write:
     per[family(name)][1] += v * 1024
-out = {'unit': 'bytes per bench step (batch 32)', 'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2',
+model = sys.argv[4] if len(sys.argv) > 4 else 'yolov5s'
+batch = int(sys.argv[5]) if len(sys.argv) > 5 else 32
+out = {'model': model, 'batch': batch, 'unit': 'bytes per bench step', 'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2',
        'kernels': {k: {'read': r, 'write': w, 'launches': n} for k, (r, w, n) in sorted(per.items())}}
 conv = [v for k, v in per.items() if 'conv' in k]
 out['conv_total'] = sum(v[0] + v[1] for v in conv)

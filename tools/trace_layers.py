@@ -7,7 +7,7 @@ with open(sys.argv[1], newline='') as f:
     for r in csv.DictReader(f):
         rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
 rows.sort()
-marks = [i for i, r in enumerate(rows) if 'focus_conv_kernel' in r[2] or 'stem2_kernel' in r[2]]
+marks = [i for i, r in enumerate(rows) if 'focus_conv_kernel' in r[2] or 'stem2_kernel' in r[2] or 'stem_conv_kernel' in r[2]]
 steps = [rows[a:b] for a, b in zip(marks[:-1], marks[1:])]
 n = max(set(len(s) for s in steps), key=[len(s) for s in steps].count)   # the steady-state launch count
 steps = [s for s in steps if len(s) == n][-20:]
