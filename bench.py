@@ -122,6 +122,7 @@ def main():
     ap.add_argument('--serial-nms', action='store_true', help='NMS on the forward\'s own stream (no overlap with the next step)')
     ap.add_argument('--profile-passes', type=int, default=5)
     ap.add_argument('--dtype', choices=('f16', 'bf16'), default='f16', help='element type of weights and activations (accumulation is fp32 either way)')
+    ap.add_argument('--no-latency', action='store_true', help='skip the batch-1 latency measurement (profiler runs: keeps other plans out of the trace)')
     ap.add_argument('--ops-json', default='', help='write the per-op list of the plan (label, kind, ms, FLOPs, minimum bytes) to this file')
     ap.add_argument('--graph', action='store_true', help='replay the forward as captured HIP graphs (one launch per forward): less host time per step, same device time')
     ap.add_argument('--fresh-outputs', action='store_true', help='allocate output tensors every step (the reference\'s behaviour) instead of reusing two sets')
@@ -319,7 +320,7 @@ def main():
         # B = 1 latency (detect.py's case): forward + NMS + host synchronisation per image, median of 30
         x1 = x[:1].contiguous()
         lat = []
-        for i in range(35):
+        for i in range(0 if args.no_latency else 35):
             torch.cuda.synchronize()
             l0 = time.perf_counter()
             z1, _ = model(x1)
@@ -327,7 +328,7 @@ def main():
             torch.cuda.synchronize()
             lat.append((time.perf_counter() - l0) * 1e3)
         lat = sorted(lat[5:])
-        latency_b1_ms = lat[len(lat) // 2]
+        latency_b1_ms = lat[len(lat) // 2] if lat else None
         top = sorted(conv, key=lambda a: -a['ms'])[:6]
         roofline = {'kernel': 'convolution kernels (stem2 / csp1 / conv_c64 / conv_c128 / conv_s2c64 / conv_p1x1 / conv_p1x1_cat / conv_ph / conv_igemm / conv_lw / conv_lin3 / conv_ws1x1 / conv3x3_ws / detect_p): all %d launches of one forward'
                               % len(conv),
@@ -345,7 +346,7 @@ def main():
             'metric': 'images/sec at 640x640 fp16 (conv fwd+decode+NMS)', 'value': round(value, 1), 'unit': 'images/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_step, 4),
             'host_enqueue_ms_per_step': round(host_enqueue_ms, 4), 'forward_ms_in_loop': round(loop_forward_ms, 4),
-            'latency_batch1_ms': round(latency_b1_ms, 4), 'rank_ms_per_step': {'min': round(min(rank_ms), 4), 'max': round(max(rank_ms), 4)},
+            'latency_batch1_ms': None if latency_b1_ms is None else round(latency_b1_ms, 4), 'rank_ms_per_step': {'min': round(min(rank_ms), 4), 'max': round(max(rank_ms), 4)},
             'higher_is_better': True, 'scaling': 'strong' if args.global_batch else 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': '%s 640x640 %s batch %d per GPU, conf %g iou %g (test.py setting), random-init weights, '
                                    'BatchNorm-calibrated, head gain %g' % (args.model, 'fp16' if args.dtype == 'f16' else 'bf16', args.batch, args.conf, args.iou, args.head_gain),
