@@ -76,7 +76,9 @@ def check():
 def timing():
     shapes = [(64, 128, 128, 80, 80, 3, 1), (64, 256, 256, 40, 40, 3, 1), (64, 512, 512, 20, 20, 3, 1), (64, 256, 512, 40, 40, 3, 2),
               (64, 320, 320, 40, 40, 3, 1), (64, 640, 640, 20, 20, 3, 1), (64, 160, 160, 80, 80, 3, 1), (64, 80, 80, 160, 160, 3, 1),
-              (64, 512, 512, 40, 40, 1, 1), (64, 1024, 1024, 20, 20, 1, 1), (64, 256, 256, 40, 40, 1, 1)]
+              (64, 512, 512, 40, 40, 1, 1), (64, 1024, 1024, 20, 20, 1, 1), (64, 256, 256, 40, 40, 1, 1),
+              (64, 96, 96, 80, 80, 3, 1), (64, 192, 192, 40, 40, 3, 1), (64, 384, 384, 20, 20, 3, 1), (64, 48, 48, 160, 160, 3, 1),
+              (64, 192, 384, 40, 40, 3, 2), (64, 80, 160, 160, 160, 3, 2), (64, 160, 160, 80, 80, 1, 1), (64, 320, 320, 80, 80, 1, 1)]
     st = _lib.current_stream()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for shp in shapes:

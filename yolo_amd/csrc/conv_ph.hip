@@ -464,6 +464,9 @@ const PhVariant kPh[] = {
     Y5_PH(2, 4, 7, 4, 16),  // 224 x 256
     Y5_PH(4, 2, 5, 4, 16),  // 320 x 128
     Y5_PH(4, 2, 5, 5, 16),  // 320 x 160
+    Y5_PH(8, 1, 4, 5, 16),  // 512 x 80
+    Y5_PH(2, 4, 8, 3, 16),  // 256 x 192
+    Y5_PH(4, 2, 8, 3, 16),  // 512 x 96
 };
 #undef Y5_PH
 
