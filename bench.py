@@ -124,6 +124,7 @@ def main():
     ap.add_argument('--dtype', choices=('f16', 'bf16'), default='f16', help='element type of weights and activations (accumulation is fp32 either way)')
     ap.add_argument('--no-latency', action='store_true', help='skip the batch-1 latency measurement (profiler runs: keeps other plans out of the trace)')
     ap.add_argument('--ops-json', default='', help='write the per-op list of the plan (label, kind, ms, FLOPs, minimum bytes) to this file')
+    ap.add_argument('--in-flight', type=int, default=3, help='steps in flight, each on its own stream with its own launch plan (yolo_amd.serving.Pipeline); 1 = forward on one stream, NMS beside the next forward on a second')
     ap.add_argument('--graph', action='store_true', help='replay the forward as captured HIP graphs (one launch per forward): less host time per step, same device time')
     ap.add_argument('--fresh-outputs', action='store_true', help='allocate output tensors every step (the reference\'s behaviour) instead of reusing two sets')
     args = ap.parse_args()
@@ -167,8 +168,12 @@ def main():
     # NMS into two sets of its own (made once, below); step k's results stay valid until step k + 2 is issued.
     # kernel variants are timed by rank 0 only; the other ranks replay its choices
     tuned_elsewhere = ydist.tune_once(lambda: model(x))
-    post, graphed = None, None
-    if not args.fresh_outputs:
+    post, graphed, pipe = None, None, None
+    if args.in_flight > 1 and not args.fresh_outputs and not args.graph and not args.serial_nms:
+        from yolo_amd import serving
+        pipe = serving.Pipeline(model, x, depth=args.in_flight, ring=2, conf_thres=args.conf, iou_thres=args.iou)
+        side = None
+    elif not args.fresh_outputs:
         engine.set_output_ring(model, 2)
         z, _ = model(x)
         if args.graph:
@@ -176,6 +181,14 @@ def main():
         post = hip_nms.PaddedNms(z.shape[0], z.shape[1], z.shape[2], z.dtype, device, conf_thres=args.conf, iou_thres=args.iou, ring=2)
 
     def step(events=None):
+        if pipe is not None:   # forward and NMS of this step on the step's own stream; other steps' kernels run beside them
+            st = pipe(x, timing=events)
+            det, count, ncand = st.det, st.count, st.n_candidates
+            if world > 1:
+                with torch.cuda.stream(st.stream):
+                    local_out[0] = (det, count)
+                    det, count = ydist.gather_detections(det, count)
+            return det, count, ncand
         if post is not None and side is not None:
             post.wait_oldest()  # the forward about to be issued overwrites the prediction that NMS call read on the other stream
         if events is not None:
@@ -273,7 +286,9 @@ def main():
         forward_ms = f0.elapsed_time(f1) / args.profile_passes
         # the per-op durations are scaled to the forward as the TIMED steps ran it (event pairs inside the loop), so the
         # roofline's denominator is a share of ms_per_step and cannot exceed it
-        event_scale = loop_forward_ms / sum(a['ms'] for a in acc)
+        # (with several steps in flight the in-loop pairs measure a forward that shares the device with other steps: the
+        # per-op durations are then scaled to the forward ALONE on the device, timed just above)
+        event_scale = (loop_forward_ms if pipe is None else forward_ms) / sum(a['ms'] for a in acc)
         for a in acc:
             a['ms'] *= event_scale
         if args.ops_json:
@@ -341,7 +356,13 @@ def main():
                     'bytes_per_forward': conv_bytes, 'bytes_basis': 'every Conv2d of the graph as one kernel (in + out + weights, fp16)' + (' + decode read/write of the head' if det else ''),
                     'plan_bytes_per_forward': plan_bytes, 'flops_per_forward': conv_flops, 'layer_list_flops': ref_flops, 'ms_per_forward': round(conv_ms, 4),
                     'mfma_tflops': round(tflops, 2), 'mfma_frac': round(tflops / PEAK_MFMA_TFLOPS, 4),
-                    'per_op_event_scale': round(event_scale, 4)}
+                    'per_op_event_scale': round(event_scale, 4),
+                    'measured': 'per-launch event durations scaled to sum to the forward as the timed steps ran it' if pipe is None else
+                                'per-launch event durations of ONE forward alone on the device (after the timed loop); in the timed loop %d steps are in flight and share the device, see in_flight' % args.in_flight}
+        if pipe is not None:   # the same bytes over the whole step time of the timed loop: a lower bound of the kernels' rate there (the NMS kernels run inside it)
+            roofline['in_flight'] = {'steps_in_flight': args.in_flight, 'ms_per_step': round(ms_step, 4),
+                                     'achieved': round(conv_bytes / (ms_step * 1e-3) / 1e9, 2), 'unit': 'GB/s', 'frac': round(conv_bytes / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                                     'mfma_tflops': round(conv_flops / (ms_step * 1e-3) / 1e12, 2), 'mfma_frac': round(conv_flops / (ms_step * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS, 4)}
         record = {
             'metric': 'images/sec at 640x640 fp16 (conv fwd+decode+NMS)', 'value': round(value, 1), 'unit': 'images/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_step, 4),
@@ -355,11 +376,12 @@ def main():
                        'tuning': 'kernel variants timed by this process' if world == 1 else 'kernel variants timed by rank 0, broadcast to the other ranks',
                        'cpus_per_rank': None if pinned is None else len(pinned),
                        'candidates_per_image': round(cand, 1), 'kept_per_image': round(kept, 1),
-                       'nms_stream': 'same stream as the forward' if side is None else 'second stream: NMS of step i beside the forward of step i+1',
-                       'outputs': 'fresh tensors every step' if post is None else 'two sets of output tensors reused in turn: no device allocation per step',
+                       'steps_in_flight': args.in_flight if pipe is not None else 1,
+                       'nms_stream': ('the step\'s own stream (%d steps in flight on %d streams, each with its own launch plan)' % (args.in_flight, args.in_flight)) if pipe is not None else 'same stream as the forward' if side is None else 'second stream: NMS of step i beside the forward of step i+1',
+                       'outputs': 'fresh tensors every step' if post is None and pipe is None else 'two sets of output tensors reused in turn: no device allocation per step',
                        'forward_issue': 'one launch per kernel' if graphed is None else 'captured HIP graphs, one launch per forward'},
             'roofline': roofline,
-            'stages': {'note': 'forward_ms and nms_ms are timed on their own after the timed loop (one stream, nothing overlapped); plan_ms / conv_ms / decode_ms are per-launch event durations scaled to sum to forward_ms_in_loop',
+            'stages': {'note': 'forward_ms and nms_ms are timed on their own after the timed loop (one stream, nothing overlapped); plan_ms / conv_ms / decode_ms are per-launch event durations scaled to sum to ' + ('forward_ms_in_loop' if pipe is None else 'forward_ms (forward_ms_in_loop is the duration of a forward that shares the device with the other steps in flight)') + '',
                        'forward_ms': round(forward_ms, 4), 'plan_ms': round(plan_ms, 4), 'conv_ms': round(conv_ms, 4), 'decode_ms': round(dec_ms, 4), 'decode_kernels': 'head conv + decode fused' if det else 'decode',
                        'nms_ms': round(nms_ms, 4),
                        'decode_hbm': {'bound': 'hbm', 'achieved': round(dec_bytes / (dec_ms * 1e-3) / 1e9, 1), 'peak': PEAK_HBM_GBS,

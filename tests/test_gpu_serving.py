@@ -150,3 +150,54 @@ def test_graphed_forward_replays_the_plan_and_refuses_a_changed_model(dev):
         model.model[0].conv.conv.weight.mul_(1.25)
     with pytest.raises(_lib.Y5Error, match='capture it again'):
         fwd()
+
+
+def test_pipeline_with_three_steps_in_flight_equals_the_serial_path_and_allocates_nothing(dev):
+    from yolo_amd.serving import Pipeline
+    model = _model(dev)
+    g = torch.Generator().manual_seed(12)
+    batches = [torch.rand(3, 3, 128, 96, generator=g).half().to(dev) for _ in range(5)]
+    want = []
+    for x in batches:
+        z, xs = model(x)
+        want.append((z.clone(),) + tuple(t.clone() for t in nms_padded(z, 0.01, 0.6, return_index=True)))
+    pipe = Pipeline(model, batches[0], depth=3, ring=2, conf_thres=0.01, iou_thres=0.6)
+    eng = engine.engine_of(model)
+    assert len(next(iter(eng.lanes.values()))) == 2, 'two more launch plans beside the model\'s own'
+    for i in range(6):                     # warm every lane and ring slot
+        pipe(batches[i % 5])
+    pipe.synchronize()
+    before, calls = _allocations(dev), engine.calls(model)
+    steps = [pipe(batches[i % 5]) for i in range(6)]       # six steps: every (lane, slot) pair once, none overwritten yet
+    assert len({s.stream for s in steps}) == 3 and len({s.z.data_ptr() for s in steps}) == 6
+    assert _allocations(dev) == before and engine.calls(model) == calls + 6
+    for i, s in enumerate(steps):
+        s.synchronize()
+        zr, dr, cr, kr, nr = want[i % 5]
+        assert torch.equal(s.z, zr) and torch.equal(s.count, cr) and torch.equal(s.n_candidates, nr)
+        for b in range(3):
+            n = int(cr[b])
+            assert torch.equal(s.det[b, :n], dr[b, :n]) and torch.equal(s.kept_index[b, :n], kr[b, :n])
+    # a change of the model drops every lane's plan; the pipeline's next step builds them again and follows the change
+    with torch.no_grad():
+        model.model[0].conv.conv.weight.mul_(0.5)
+    z_new = model(batches[1])[0].clone()
+    assert not eng.lanes
+    s = pipe(batches[1]).synchronize()
+    s = pipe(batches[1]).synchronize()     # a lane other than 0
+    assert torch.equal(s.z, z_new) and not torch.equal(s.z, want[1][0])
+    with pytest.raises(ValueError):
+        pipe(batches[0][:2])
+
+
+def test_pipeline_copy_input_and_forward_only(dev):
+    from yolo_amd.serving import Pipeline
+    model = _model(dev)
+    x = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(3)).half().to(dev)
+    ref = model(x)[0].clone()
+    pipe = Pipeline(model, x, depth=2, ring=1, copy_input=True, nms=False)
+    buf = x.clone()
+    s = pipe(buf)
+    buf.zero_()                            # the pipeline read its own copy
+    s.wait()
+    assert s.det is None and torch.equal(s.z, ref)

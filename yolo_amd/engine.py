@@ -275,6 +275,16 @@ def run(model, x):
     return _engine_of(model).forward(x)
 
 
+def run_lane(model, x, lane=0, stream=None):
+    """try_run on launch plan number `lane` and on `stream`: forwards of one model issued on different streams need
+    different lanes (a plan's activation buffers serve one forward at a time).  Lane 0 is the plan model(x) uses."""
+    plan = _plan_if_eligible(model, x)
+    if plan is None:
+        return None
+    eng = _ENGINES[model]
+    return eng._run(eng.lane_plan(plan, x, lane), x, stream)
+
+
 def _engine_of(model):
     eng = _ENGINES.get(model)
     if eng is None:
@@ -290,7 +300,7 @@ def set_output_ring(model, n):
     tensors per forward, the default (environment: Y5_OUTPUT_RING)."""
     eng = _engine_of(model)
     eng.output_ring = max(0, int(n))
-    for plan in eng.plans.values():
+    for plan in list(eng.plans.values()) + [p for extra in eng.lanes.values() for p in extra]:
         plan.set_ring(eng.output_ring)
 
 
@@ -1434,7 +1444,8 @@ class Plan:
             xs = [torch.empty(s, dtype=self.dtype, device=self.device) for s in self.x_shapes]
             self._ring.append((z, xs, self._ext(z, z, xs)))
 
-    def run(self, x):
+    def run(self, x, stream=None):
+        """Issue the forward on `stream` (a torch.cuda.Stream; default: the current one)."""
         ring = self._ring
         if ring:
             z, xs, ext = ring[self._turn]
@@ -1444,7 +1455,7 @@ class Plan:
             z = torch.empty(self.z_shape, dtype=self.dtype, device=self.device)
             xs = [torch.empty(s, dtype=self.dtype, device=self.device) for s in self.x_shapes]
             ext = self._ext(x, z, xs)
-        _lib.check(self.lib.y5_plan_run(self.handle, ext, len(ext), _lib.current_stream()))
+        _lib.check(self.lib.y5_plan_run(self.handle, ext, len(ext), _lib.current_stream() if stream is None else C.c_void_p(stream.cuda_stream)))
         return z, xs
 
     def profile(self, x):
@@ -1494,6 +1505,7 @@ class Engine:
         self.calls = 0            # forwards executed by HIP kernels (read by tests)
         self.walks = 0            # full walks of the model (tests: the steady state does none)
         self.output_ring = int(os.environ.get('Y5_OUTPUT_RING', '0'))  # sets of output tensors each plan reuses; 0 = fresh tensors
+        self.lanes = {}           # plan key -> further plans for the same input (lane_plan)
         self._state = None
 
     @property
@@ -1540,6 +1552,7 @@ class Engine:
             for p in self.plans.values():
                 p.close()
             self.plans.clear()
+            self._drop_lanes()
             self.signature = st.signature
         return st
 
@@ -1562,9 +1575,10 @@ class Engine:
             plan.set_ring(self.output_ring)
             self.plans[key] = plan
             while len(self.plans) > max(1, MAX_PLANS):  # a rectangular-batch loader feeds many shapes: bound the buffers held
-                _, old = self.plans.popitem(last=False)
+                old_key, old = self.plans.popitem(last=False)
                 torch.cuda.synchronize(x.device)  # launches of the evicted plan may still be in flight on any stream
                 old.close()
+                self._drop_lanes(old_key)
         else:
             self.plans.move_to_end(key)
         return plan
@@ -1573,13 +1587,33 @@ class Engine:
         st = self.state()
         return st.types_ok and self._plan(x, st) is not None
 
-    def _run(self, plan, x):
+    def _run(self, plan, x, stream=None):
         if not plan.hwc:
             x = x.contiguous()
         with torch.cuda.device(x.device):
-            z, xs = plan.run(x)
+            z, xs = plan.run(x, stream)
         self.calls += 1
         return z, xs
+
+    def lane_plan(self, plan, x, lane):
+        """Launch plan number `lane` for the input that `plan` (lane 0, the one model(x) uses) was built for.  Lanes are
+        independent copies of the plan - own activation buffers, own outputs - so that forwards issued on different streams
+        can be in flight together.  They live and die with the model's state like every plan."""
+        if lane == 0:
+            return plan
+        key = next(k for k, p in self.plans.items() if p is plan)
+        extra = self.lanes.setdefault(key, [])
+        while len(extra) < lane:
+            with torch.cuda.device(x.device):
+                p = Plan(self.model, x)
+            p.set_ring(self.output_ring)
+            extra.append(p)
+        return extra[lane - 1]
+
+    def _drop_lanes(self, key=None):
+        for k in ([key] if key is not None else list(self.lanes)):
+            for p in self.lanes.pop(k, []):
+                p.close()
 
     def forward(self, x):
         plan = self._plan(x)

@@ -143,7 +143,7 @@ class PaddedNms:
     workspace allocated here."""
 
     def __init__(self, batch, n_rows, no, dtype=torch.float16, device='cuda', conf_thres=0.1, iou_thres=0.6, classes=None,
-                 agnostic=False, max_det=MAX_DET, max_candidates=None, ring=1, merge=False):
+                 agnostic=False, max_det=MAX_DET, max_candidates=None, ring=1, merge=False, private_workspace=False):
         if dtype not in _PRED_DTYPE:
             raise ValueError('PaddedNms takes fp16, bf16 or fp32 predictions')
         lib = _lib.lib()
@@ -154,7 +154,9 @@ class PaddedNms:
         nc = no - 5
         cap = int(max_candidates or min(n_rows * nc, DEFAULT_CANDIDATES))
         self.mask = _class_mask(classes, nc, self.dev)
-        self.builtin = _fits_builtin(lib, batch, cap)
+        # private_workspace: never the library's built-in array (which all calls on one GPU share): for instances whose
+        # calls overlap in time with other NMS calls on the same GPU (one instance per stream)
+        self.builtin = _fits_builtin(lib, batch, cap) and not private_workspace
         self.fn = lib.y5_nms_batched_noalloc if self.builtin else lib.y5_nms_batched
         self.ws = None
         if not self.builtin:
@@ -176,10 +178,11 @@ class PaddedNms:
         self.turn = 0
         self.calls = 0
 
-    def __call__(self, prediction, stream=None):
+    def __call__(self, prediction, stream=None, after_current=True):
         """(det, count, kept_index, n_candidates) of `prediction`, computed on the current stream, or on `stream` (a
         torch.cuda.Stream) ordered after the work already issued on the current one: the current stream does not wait for
-        it, so the next forward runs beside this NMS; the results then belong to `stream`."""
+        it, so the next forward runs beside this NMS; the results then belong to `stream`.  after_current=False skips that
+        ordering: for a prediction that was itself produced on `stream`."""
         if (tuple(prediction.shape) != self.shape or prediction.dtype is not self.dtype or prediction.device != self.dev
                 or not prediction.is_contiguous()):
             raise ValueError('PaddedNms was built for a contiguous %s %s tensor on %s' % (self.shape, self.dtype, self.dev))
@@ -191,7 +194,8 @@ class PaddedNms:
             _lib.check(self.fn(ref, _lib.current_stream()))
             done.record()
         else:
-            stream.wait_stream(torch.cuda.current_stream(self.dev))
+            if after_current:
+                stream.wait_stream(torch.cuda.current_stream(self.dev))
             _lib.check(self.fn(ref, C.c_void_p(stream.cuda_stream)))
             done.record(stream)
         return bufs
