@@ -511,9 +511,9 @@ def test_small_class_count_model_runs_on_the_engine(dev, nc):
 
 
 @pytest.mark.parametrize('agnostic', [False, True])
-def test_merge_step_kernel_against_the_reference_stage_list(dev, agnostic):
-    """merge=True on the GPU is one kernel after the selection; the reference's stage list (utils/utils.py:570-645, here
-    on the CPU with the host greedy NMS) is the check.  Images: a dense one (merging and redundancy both act), one with a
+def test_merge_step_kernel_against_the_oracle(dev, agnostic):
+    """merge=True on the GPU is one kernel after the selection; the numpy oracle (pinned to the reference's output by
+    tests/golden/nms_merge.npz) is the check.  Images: a dense one (merging and redundancy both act), one with a
     single candidate and an empty one (no merge: n <= 1), one with more than 3000 candidates (no merge: n >= 3E3).
     Counts, confidences and classes are exact; merged corners agree to the summation order of the reference's fp32
     matrix product."""
@@ -524,23 +524,24 @@ def test_merge_step_kernel_against_the_reference_stage_list(dev, agnostic):
     empty = torch.zeros(1, 3000, 9)
     many = synth_prediction(22, 1, 3000, 4, frac=0.9)
     pred = torch.cat((dense, single, empty, many), 0)
-    ref = yu._nms_stage_list(pred.clone(), 0.1, 0.5, True, None, agnostic, yu._greedy_nms_host)
-    plain = yu._nms_stage_list(pred.clone(), 0.1, 0.5, False, None, agnostic, yu._greedy_nms_host)
+    ref = y5ref.non_max_suppression(pred.numpy(), 0.1, 0.5, agnostic=agnostic, merge=True, nms_fn=nms_c.nms)
+    plain = y5ref.non_max_suppression(pred.numpy(), 0.1, 0.5, agnostic=agnostic, nms_fn=nms_c.nms)
     det, cnt, kept, ncand = hip_nms.nms_padded(pred.to(dev), 0.1, 0.5, agnostic=agnostic, merge=True, return_index=True)
     assert 1 < int(ncand[0]) < 3000 and int(ncand[1]) == 1 and int(ncand[2]) == 0 and int(ncand[3]) >= 3000
-    assert ref[0].shape[0] < plain[0].shape[0], 'the redundancy filter must drop something in the dense image'
-    assert not torch.equal(ref[0][:, :4], plain[0][:ref[0].shape[0], :4])
-    assert torch.equal(ref[3], plain[3]) and ref[2] is None
-    for b, r in enumerate(ref):
-        n = 0 if r is None else r.shape[0]
-        assert int(cnt[b]) == n
-        if n:
-            got = det[b, :n].cpu()
-            assert torch.equal(got[:, 4:], r[:, 4:])
-            assert torch.allclose(got[:, :4], r[:, :4], rtol=1e-5, atol=1e-3)
-            nc = pred.shape[2] - 5
-            idx = kept[b, :n].cpu().long()
-            assert torch.equal((idx % nc).float(), r[:, 5])  # kept_index follows the compaction
+    assert len(ref[0][0]) < len(plain[0][0]), 'the redundancy filter must drop something in the dense image'
+    assert not np.array_equal(ref[0][0][:, :4], plain[0][0][:len(ref[0][0]), :4])
+    assert np.array_equal(ref[3][0], plain[3][0]) and len(ref[2][0]) == 0
+    for b, (rdet, rflat, rn) in enumerate(ref):
+        n = len(rdet)
+        assert int(cnt[b]) == n and int(ncand[b]) == rn
+        got = det[b, :n].cpu().numpy()
+        assert np.array_equal(got[:, 4:], rdet[:, 4:])
+        assert np.allclose(got[:, :4], rdet[:, :4], rtol=1e-5, atol=1e-3)
+        assert np.array_equal(kept[b, :n].cpu().numpy(), rflat)          # kept_index follows the compaction
         assert bool((det[b, n:] == 0).all()) and bool((kept[b, n:] == -1).all())
+    # the mirror's CPU stage list (the reference's own statements) agrees with the oracle on the same input
+    host = yu._nms_stage_list(pred.clone(), 0.1, 0.5, True, None, agnostic, yu._greedy_nms_host)
+    for b, h in enumerate(host):
+        assert (h is None and len(ref[b][0]) == 0) or np.allclose(h.numpy(), ref[b][0], rtol=1e-5, atol=1e-3)
     out = yu.non_max_suppression(pred.to(dev), 0.1, 0.5, merge=True, agnostic=agnostic)   # the list API takes the same path
     assert out[2] is None and all(torch.equal(o.cpu(), det[b, :o.shape[0]].cpu()) for b, o in enumerate(out) if o is not None)

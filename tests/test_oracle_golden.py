@@ -62,6 +62,21 @@ def test_nms_stage_list_matches_reference(name, impl):
         assert np.array_equal(det, z['det'][b, :len(det)])
 
 
+def test_merge_nms_oracle_matches_reference():
+    """merge=True (utils/utils.py:630-639) in the numpy oracle against what the reference produced: same rows kept (the
+    redundancy filter is exact), same confidences and classes, merged corners to the summation order of the reference's
+    fp32 matrix product."""
+    z = util.golden('nms_merge')
+    out = y5ref.non_max_suppression(z['pred'], float(z['conf']), float(z['iou']), merge=True)
+    plain = y5ref.non_max_suppression(z['pred'], float(z['conf']), float(z['iou']))
+    for b, (det, flat, ncand) in enumerate(out):
+        n = int(z['count'][b])
+        assert len(det) == n and 1 < ncand < 3000
+        assert np.array_equal(det[:, 4:], z['det'][b, :n, 4:])
+        assert np.allclose(det[:, :4], z['det'][b, :n, :4], rtol=1e-5, atol=1e-4)
+        assert len(plain[b][0]) > n and not np.array_equal(plain[b][0][:n, :4], det[:, :4])   # the step did something
+
+
 def test_c_and_numpy_box_nms_agree_on_random_boxes():
     rng = np.random.default_rng(0)
     for n, thr in ((1, 0.5), (50, 0.3), (2000, 0.6), (3000, 0.65)):
