@@ -171,9 +171,14 @@ def main():
     post, graphed, pipe = None, None, None
     if args.in_flight > 1 and not args.fresh_outputs and not args.graph and not args.serial_nms:
         from yolo_amd import serving
-        pipe = serving.Pipeline(model, x, depth=args.in_flight, ring=2, conf_thres=args.conf, iou_thres=args.iou)
-        side = None
-    elif not args.fresh_outputs:
+        try:   # every step in flight has activation buffers of its own: a very large batch may not fit three times
+            pipe = serving.Pipeline(model, x, depth=args.in_flight, ring=2, conf_thres=args.conf, iou_thres=args.iou)
+            side = None
+        except torch.cuda.OutOfMemoryError:
+            engine.engine_of(model)._drop_lanes()
+            torch.cuda.empty_cache()
+            args.in_flight = 1
+    if pipe is None and not args.fresh_outputs:
         engine.set_output_ring(model, 2)
         z, _ = model(x)
         if args.graph:
