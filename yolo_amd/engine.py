@@ -1549,6 +1549,8 @@ class Engine:
                 return st
         st = self._state = self._walk()
         if st.signature != self.signature:
+            if self.lanes:  # forwards of the old plans may be in flight on other streams than the current one
+                torch.cuda.synchronize()
             for p in self.plans.values():
                 p.close()
             self.plans.clear()

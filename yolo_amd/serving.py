@@ -41,7 +41,9 @@ class Pipeline:
     issued on the caller's current stream; the caller must leave it untouched until step.done (copy_input=True makes the
     pipeline copy it into a buffer of its own first, on the caller's stream: one more pass over the images, and the
     caller may reuse the batch tensor at once).
-    nms=False leaves the NMS out (step.det etc. are None): forward only."""
+    nms=False leaves the NMS out (step.det etc. are None): forward only.
+    Building a Pipeline switches the model's launch plans to ring outputs (engine.set_output_ring(model, ring)): model(x)
+    called directly afterwards also returns tensors that are reused `ring` forwards later."""
 
     def __init__(self, model, example, depth=3, ring=2, conf_thres=0.1, iou_thres=0.6, classes=None, agnostic=False, merge=False,
                  max_det=MAX_DET, max_candidates=None, copy_input=False, nms=True):
