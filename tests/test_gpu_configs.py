@@ -162,3 +162,22 @@ def test_config5_unfused_pruned_model_as_fp_test_runs_it(dev):
     assert engine.calls(model) == 1
     zr, xr = _oracle('yolov5s_ori', model, x[:1])
     agree(z[:1], zr, 0.90)
+
+
+@pytest.mark.parametrize('mode', ['0', 'force'])
+def test_config5_with_and_without_widths_padded_to_regular_ones(dev, mode, monkeypatch):
+    """The engine builds the plan of a pruned model twice - channel counts padded to multiples of 8, and to regular widths
+    (zero channels, zero weight rows) - and keeps the faster one.  Either plan against the oracle."""
+    monkeypatch.setenv('Y5_PAD_REGULAR', mode)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    model = _prepare('yolov5s_ori', dev, pruned=True)
+    x = torch.rand(3, 3, 640, 640, generator=torch.Generator().manual_seed(4)).half().to(dev)
+    z, xs = model(x)
+    plan = next(iter(engine.engine_of(model).plans.values()))
+    assert plan.regular_widths == (mode == 'force')
+    zr, xr = _oracle('yolov5s_ori', model, x[:1])
+    for a, b in zip(xs, xr):
+        agree(a[:1], b, 0.60)
+    agree(z[:1], zr, 0.90)
+    z2, _ = model(torch.roll(x, 1, 0))
+    assert torch.equal(z2, torch.roll(z, 1, 0))

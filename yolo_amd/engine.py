@@ -175,8 +175,33 @@ class disabled:
         _DISABLED[0] -= 1
 
 
+_PAD_REGULAR = [False]  # while a Plan is being built: pad channel counts to regular widths instead of multiples of 8
+
+
 def pad8(c):
+    """Channels a tensor of c logical channels occupies in memory: the next multiple of 8 (16-byte vectors), or - for the
+    plans of a model with irregular widths that measured faster that way - the next regular width: 32, 64, 128, ... when
+    that is within a third of c, else the next multiple of 32.  The extra channels hold zeros (zero weight rows, zero bias);
+    the kernels written for regular widths (persistent 1x1, weights-in-registers chains, whole blocks) then apply to the
+    channel plans filter pruning leaves behind (filter_pruning/torch_pruning/prune/structured.py:48-60: 13, 25, 55, 119 ...)."""
+    if _PAD_REGULAR[0] and c > 16:
+        for w in (32, 64, 128, 256, 512, 1024):
+            if c <= w <= c * 1.34:
+                return w
+        return (c + 31) // 32 * 32
     return (c + 7) // 8 * 8
+
+
+def _irregular_widths(model):
+    """True when some convolution of the model has a channel count that is not a multiple of 32 (the Detect convolutions
+    and the image side of the first layer aside): a pruned channel plan."""
+    from yolo_amd.models.yolo import Detect
+    head = model.model[-1] if isinstance(model.model[-1], Detect) else None
+    skip = set(id(m) for m in head.m) if head is not None else set()
+    for m in model.modules():
+        if isinstance(m, nn.Conv2d) and id(m) not in skip and (m.out_channels % 32 or (m.in_channels % 32 and m.in_channels > 16)):
+            return True
+    return False
 
 
 def _supported_types():
@@ -459,6 +484,7 @@ class Plan:
         self.labels = []        # one human-readable label per op
         self._defer = None      # list collecting (label, descriptor, input) instead of recording, see _emit_conv
         self._ring, self._turn = [], 0  # sets of output tensors handed out in turn (set_ring); empty: fresh tensors per run
+        self.regular_widths = False     # built with channel counts padded to regular widths (pad8)
         self.homes = {}
         handle = C.c_void_p()
         _lib.check(self.lib.y5_plan_create(C.byref(handle)))
@@ -1571,6 +1597,8 @@ class Engine:
             try:
                 with torch.cuda.device(x.device):
                     plan = Plan(self.model, x)
+                    if os.environ.get('Y5_PAD_REGULAR', '1') != '0' and not plan.bf16 and _irregular_widths(self.model):
+                        plan = self._faster_padding(plan, x)
             except Unsupported as e:
                 self.unsupported = ((sig, key), str(e))
                 return None
@@ -1597,6 +1625,34 @@ class Engine:
         self.calls += 1
         return z, xs
 
+    def _faster_padding(self, plan, x):
+        """A model with irregular channel counts: build its plan a second time with the widths padded to regular ones
+        (pad8) and keep whichever of the two runs the forward faster; lanes built later follow the choice."""
+        def ms(p):
+            xs = x if p.hwc else x.contiguous()
+            for _ in range(2):
+                p.run(xs)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(8):
+                p.run(xs)
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) / 8
+        _PAD_REGULAR[0] = True
+        try:
+            wide = Plan(self.model, x)
+        except Unsupported:
+            return plan
+        finally:
+            _PAD_REGULAR[0] = False
+        wide.regular_widths = True
+        a, b = ms(plan), ms(wide)
+        keep, drop = (wide, plan) if b < a or os.environ.get('Y5_PAD_REGULAR') == 'force' else (plan, wide)
+        torch.cuda.synchronize()
+        drop.close()
+        return keep
+
     def lane_plan(self, plan, x, lane):
         """Launch plan number `lane` for the input that `plan` (lane 0, the one model(x) uses) was built for.  Lanes are
         independent copies of the plan - own activation buffers, own outputs - so that forwards issued on different streams
@@ -1607,7 +1663,12 @@ class Engine:
         extra = self.lanes.setdefault(key, [])
         while len(extra) < lane:
             with torch.cuda.device(x.device):
-                p = Plan(self.model, x)
+                _PAD_REGULAR[0] = plan.regular_widths
+                try:
+                    p = Plan(self.model, x)
+                finally:
+                    _PAD_REGULAR[0] = False
+                p.regular_widths = plan.regular_widths
             p.set_ring(self.output_ring)
             extra.append(p)
         return extra[lane - 1]
