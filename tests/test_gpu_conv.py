@@ -208,7 +208,17 @@ VARIANT_SHAPES = [
     (32, 128, 128, 40, 40, 1, 1),
     (5, 256, 128, 33, 31, 1, 1),
     (5, 128, 256, 33, 31, 1, 1),
+    # the same kernel on widths inside a power-of-two layout (yolov5m: 96, 192; yolov5x: 160): pieces and channel blocks past
+    # the real width are skipped
+    (3, 160, 160, 21, 23, 1, 1),
+    (16, 160, 160, 40, 40, 1, 1),
+    (2, 192, 192, 37, 5, 1, 1),
+    (5, 96, 96, 33, 31, 1, 1),
+    (3, 192, 96, 17, 19, 1, 1),
+    (2, 320, 160, 33, 31, 1, 1),
+    (9, 384, 192, 20, 20, 1, 1),
 ]
+INNER_1X1 = {(160, 160): True, (192, 192): True, (96, 96): True, (192, 96): False, (320, 160): False, (384, 192): False}  # -> both tile sizes?
 
 
 @pytest.mark.parametrize('shape', VARIANT_SHAPES, ids=lambda s: 'x'.join(map(str, s)))
@@ -249,6 +259,9 @@ def test_every_kernel_variant_that_takes_the_shape(dev, shape):
         assert run_conv(dev, x, w, bias=bias, slope=0.1, stride=s, variant=v) is not None, 'the phased kernels take every 1x1 / 3x3 shape'
     if (Ci, Co, k, s) == (32, 64, 3, 2) and (H // 2) % 8 == 0 and (W // 2) % 16 == 0:
         assert run_conv(dev, x, w, bias=bias, slope=0.1, stride=s, variant=nv) is not None, 'the persistent stride-2 kernel takes this shape'
+    if k == 1 and (Ci, Co) in INNER_1X1:
+        assert run_conv(dev, x, w, bias=bias, slope=0.1, stride=s, variant=nv - 3) is not None, 'the persistent 1x1 kernel takes this shape'
+        assert (run_conv(dev, x, w, bias=bias, slope=0.1, stride=s, variant=nv - 4) is not None) == INNER_1X1[(Ci, Co)]
     if k == 1 and Ci in (128, 256) and Co in (128, 256):
         assert run_conv(dev, x, w, bias=bias, slope=0.1, stride=s, variant=nv - 3) is not None, 'the persistent 1x1 kernel takes this shape'
         assert (run_conv(dev, x, w, bias=bias, slope=0.1, stride=s, variant=nv - 4) is not None) == ((Ci, Co) != (256, 128))

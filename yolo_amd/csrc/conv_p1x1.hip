@@ -26,6 +26,7 @@ struct P1Args {
     const float *bias, *scale, *shift;
     int w_ld, x_ld, y_ld, x_bytes;
     int npix, ntiles;
+    int cout;   // output channels with parameters behind them (conv_p1x1_kernel: the real width inside the 32 NCW layout)
     float slope;
 };
 
@@ -43,9 +44,14 @@ struct P1Cfg {
     static_assert(SMEM <= 160 * 1024, "fits the CU's LDS");
 };
 
-template <int KS, int NCW, int NT, int F>
+// KSR <= KS and NCR <= NCW: the layer's REAL width inside the layout (160 input channels in rows laid out for 256: the
+// swizzle needs a power-of-two number of slots per staged pixel; 160 output channels on the wave grid of 256).  Slots past
+// the real width are never fetched (their lanes of a copy ask for an out-of-range address and get zeros), K-steps past it
+// are not multiplied, waves whose channel block lies past it only copy.
+template <int KS, int NCW, int NT, int F, int KSR = KS, int NCR = NCW>
 __global__ __launch_bounds__(NTH) void conv_p1x1_kernel(const P1Args a) {
     typedef P1Cfg<KS, NCW, NT> Cfg;
+    static_assert(KSR >= 1 && KSR <= KS && NCR >= 1 && NCR <= NCW, "real width inside the layout");
     constexpr int MYP = Cfg::MYP;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int t = threadIdx.x, lane = t & 63, lr = lane & 31, lh = lane >> 5;
@@ -59,7 +65,7 @@ __global__ __launch_bounds__(NTH) void conv_p1x1_kernel(const P1Args a) {
     float* prm = reinterpret_cast<float*>(smem + Cfg::PRM0);
     static_assert(Cfg::CO <= NTH, "one channel's parameters per thread");
     float pv[3] = {0.f, 1.f, 0.f};  // fetched here, stored once the weights have landed: one round trip for everything
-    if (t < Cfg::CO) {
+    if (t < Cfg::CO && t < a.cout) {
         if (a.bias) pv[0] = a.bias[t];
         if (a.scale) {
             pv[1] = a.scale[t];
@@ -68,6 +74,7 @@ __global__ __launch_bounds__(NTH) void conv_p1x1_kernel(const P1Args a) {
     }
 
     const int mt = wave % NCW, pg = wave / NCW;  // output channels [32 mt, +32); pixels [32 NT pg, +32 NT) of the tile
+    const bool works = NCR == NCW || mt < NCR;   // wave-uniform: this wave's channel block exists
 
     // ---------------------------------------------------------------------- the copies: wave w issues pieces w, w + 8, ...
     const i32x4 xr = make_buf(a.x, a.x_bytes);
@@ -75,8 +82,9 @@ __global__ __launch_bounds__(NTH) void conv_p1x1_kernel(const P1Args a) {
 #pragma unroll
     for (int j = 0; j < MYP; ++j) {
         const int slot = (wave + NWC * j) * 64 + lane, px = slot / Cfg::SLOTS, sp = slot % Cfg::SLOTS;
-        cpx[j] = px;
-        rel[j] = px * (a.x_ld * 2) + ((sp ^ (px & 15)) << 4);
+        const int src = sp ^ (px & 15);           // the 16-byte piece of the pixel's channels that LDS slot sp holds
+        cpx[j] = KSR == KS || src < 2 * KSR ? px : 0x7fffffff;   // pieces past the real width: never inside the run
+        rel[j] = px * (a.x_ld * 2) + (src << 4);
     }
     auto issue = [&](int tile, int buf) {
         const int pix0 = run0 + tile * Cfg::TP, left = run1 - pix0;
@@ -98,12 +106,12 @@ __global__ __launch_bounds__(NTH) void conv_p1x1_kernel(const P1Args a) {
     // The first tile's pieces go out before the weights are fetched, so that both arrive in one round trip (parameters,
     // then weights, then copies cost the launch three).
     if (first < last) issue(first, 0);
-    f16x8 wf[KS];
+    f16x8 wf[KSR];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) wf[ks] = *reinterpret_cast<const f16x8*>(a.w + (size_t)(mt * 32 + perm_row(lr)) * a.w_ld + ks * 16 + lh * 8);
+    for (int ks = 0; ks < KSR; ++ks) wf[ks] = *reinterpret_cast<const f16x8*>(a.w + (size_t)((works ? mt : 0) * 32 + perm_row(lr)) * a.w_ld + ks * 16 + lh * 8);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // from here on the only loads in flight are the copies counted below
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(wf[ks]));  // in registers: nothing in the tile loop waits for them
+    for (int ks = 0; ks < KSR; ++ks) asm volatile("" : "+v"(wf[ks]));  // in registers: nothing in the tile loop waits for them
     if (t < Cfg::CO) {
         prm[t] = pv[0];
         prm[Cfg::CO + t] = pv[1];
@@ -123,13 +131,15 @@ __global__ __launch_bounds__(NTH) void conv_p1x1_kernel(const P1Args a) {
         }
         const unsigned char* X = smem + buf * Cfg::X_BYTES;
         f16x8 lo[NT], hi[NT];
+        if (works) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            f32x16 acc = zero16();
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x16 acc = zero16();
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], *reinterpret_cast<const f16x8*>(X + (uoff[nt] ^ (ks << 5))), acc, 0, 0, 0);
-            finish<F>(acc, q, a.slope, negzero, lo[nt], hi[nt]);
+                for (int ks = 0; ks < KSR; ++ks)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], *reinterpret_cast<const f16x8*>(X + (uoff[nt] ^ (ks << 5))), acc, 0, 0, 0);
+                finish<F>(acc, q, a.slope, negzero, lo[nt], hi[nt]);
+            }
         }
         // the next tile's pieces (issued a whole tile ago) must have landed before the next barrier; the pieces issued at the
         // top of this tile are younger and may stay in flight, this tile's stores are issued after the wait
@@ -141,7 +151,7 @@ __global__ __launch_bounds__(NTH) void conv_p1x1_kernel(const P1Args a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int pix = pix0 + (pg * NT + nt) * 32 + lr;
-            if (pix < run1) {
+            if (works && pix < run1) {
                 f16* yp = a.y + (size_t)pix * a.y_ld + mt * 32 + 16 * lh;
                 *reinterpret_cast<f16x8*>(yp) = lo[nt];
                 *reinterpret_cast<f16x8*>(yp + 8) = hi[nt];
@@ -501,25 +511,26 @@ int cu_count() {  // compute units of the current device (one persistent workgro
     return n;
 }
 
-template <int KS, int NCW, int NT, int F>
+template <int KS, int NCW, int NT, int F, int KSR, int NCR>
 int launch_f(P1Args& a, hipStream_t s) {
     typedef P1Cfg<KS, NCW, NT> Cfg;
     static std::atomic<unsigned long long> attr_set{0};
     const unsigned long long bit = 1ull << y5_current_device();
     if (!(attr_set.load() & bit)) {
-        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p1x1_kernel<KS, NCW, NT, F>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_p1x1_kernel<KS, NCW, NT, F, KSR, NCR>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
         attr_set.fetch_or(bit);
     }
     a.ntiles = (a.npix + Cfg::TP - 1) / Cfg::TP;
     const int cus = cu_count();
-    hipLaunchKernelGGL((conv_p1x1_kernel<KS, NCW, NT, F>), dim3((unsigned)(a.ntiles < cus ? a.ntiles : cus)), dim3(NTH), (size_t)Cfg::SMEM, s, a);
+    hipLaunchKernelGGL((conv_p1x1_kernel<KS, NCW, NT, F, KSR, NCR>), dim3((unsigned)(a.ntiles < cus ? a.ntiles : cus)), dim3(NTH), (size_t)Cfg::SMEM, s, a);
     Y5_LAUNCH_CHECK("conv_p1x1_kernel");
     return Y5_OK;
 }
 
-template <int KS, int NCW, int NT>
+template <int KS, int NCW, int NT, int KSR = KS, int NCR = NCW>
 int launch(P1Args& a, int f, hipStream_t s) {
-    return f == 0 ? launch_f<KS, NCW, NT, 0>(a, s) : f == 1 ? launch_f<KS, NCW, NT, 1>(a, s) : f == 2 ? launch_f<KS, NCW, NT, 2>(a, s) : launch_f<KS, NCW, NT, 3>(a, s);
+    return f == 0 ? launch_f<KS, NCW, NT, 0, KSR, NCR>(a, s) : f == 1 ? launch_f<KS, NCW, NT, 1, KSR, NCR>(a, s)
+         : f == 2 ? launch_f<KS, NCW, NT, 2, KSR, NCR>(a, s) : launch_f<KS, NCW, NT, 3, KSR, NCR>(a, s);
 }
 
 template <int KS, int NCW, int KS2, int NCW2>
@@ -563,8 +574,12 @@ int y5_conv_p1x1_count() { return 2; }
 // status in *rc.  d was validated by y5_launch_conv.
 int y5_try_conv_p1x1(const y5_conv_desc& d, hipStream_t s, int which, int* rc) {
     if (which < 1 || which > 2 || d.ksize != 1 || d.stride != 1 || d.pad != 0 || d.res) return 0;
-    if ((d.cin != 128 && d.cin != 256) || (d.cout != 128 && d.cout != 256)) return 0;
-    if (d.w_rows < d.cout || d.kpad < d.cin) return 0;
+    const bool pow2 = (d.cin == 128 || d.cin == 256) && (d.cout == 128 || d.cout == 256);
+    // widths inside a power-of-two layout: yolov5m (96, 192) and yolov5x (160) 1x1 layers
+    const bool inner = (d.cin == 160 && d.cout == 160) || (d.cin == 192 && d.cout == 192) || (d.cin == 96 && d.cout == 96) ||
+                       (d.cin == 192 && d.cout == 96) || (d.cin == 320 && d.cout == 160) || (d.cin == 384 && d.cout == 192);
+    if (!pow2 && !inner) return 0;
+    if (d.w_rows < (d.cout + 31) / 32 * 32 || d.kpad < d.cin) return 0;
     const long long npix = (long long)d.batch * d.h * d.w_in;
     const long long xb = ((npix - 1) * d.x_ld + d.cin) * 2;
     if (npix <= 0 || npix >= 0x7fffffffLL || xb >= 0x7fffffffLL) return 0;
@@ -575,8 +590,22 @@ int y5_try_conv_p1x1(const y5_conv_desc& d, hipStream_t s, int which, int* rc) {
     a.bias = d.bias; a.scale = d.scale; a.shift = d.shift;
     a.w_ld = d.kpad; a.x_ld = d.x_ld; a.y_ld = d.y_ld; a.x_bytes = (int)xb;
     a.npix = (int)npix;
+    a.cout = d.cout;
     a.slope = d.act == Y5_ACT_LEAKY ? d.slope : 1.f;
     const int f = (d.bias ? 1 : 0) | (d.scale ? 2 : 0);
+    if (inner) {
+        if (d.cin == 160 && d.cout == 160) *rc = which == 1 ? launch<16, 8, 2, 10, 5>(a, f, s) : launch<16, 8, 1, 10, 5>(a, f, s);
+        else if (d.cin == 192 && d.cout == 192) *rc = which == 1 ? launch<16, 8, 2, 12, 6>(a, f, s) : launch<16, 8, 1, 12, 6>(a, f, s);
+        else if (d.cin == 96 && d.cout == 96) *rc = which == 1 ? launch<8, 4, 2, 6, 3>(a, f, s) : launch<8, 4, 1, 6, 3>(a, f, s);
+        else if (d.cin == 192 && d.cout == 96) {
+            if (which == 1) return 0;
+            *rc = launch<16, 4, 1, 12, 3>(a, f, s);
+        } else {  // 320 -> 160 and 384 -> 192: rows of 64 slots, 32-pixel tiles
+            if (which == 1) return 0;
+            *rc = d.cin == 320 ? launch<32, 8, 1, 20, 5>(a, f, s) : launch<32, 8, 1, 24, 6>(a, f, s);
+        }
+        return 1;
+    }
     if (d.cin == 256 && d.cout == 256) *rc = which == 1 ? launch<16, 8, 2>(a, f, s) : launch<16, 8, 1>(a, f, s);
     else if (d.cin == 128 && d.cout == 128) *rc = which == 1 ? launch<8, 4, 2>(a, f, s) : launch<8, 4, 1>(a, f, s);
     else if (d.cin == 256 && d.cout == 128) {
