@@ -378,7 +378,9 @@ def test_nms_is_idempotent_on_its_own_output(dev):
     assert keep.tolist() == list(range(n))
 
 
-@pytest.mark.parametrize('shape', [(2, 128, 16, 24), (3, 256, 20, 20), (1, 72, 7, 9), (2, 72, 8, 8), (9, 128, 80, 80), (5, 256, 40, 40), (3, 128, 20, 12)],
+@pytest.mark.parametrize('shape', [(2, 128, 16, 24), (3, 256, 20, 20), (1, 72, 7, 9), (2, 72, 8, 8), (9, 128, 80, 80), (5, 256, 40, 40), (3, 128, 20, 12),
+                                   # the persistent kernel on head widths inside a power-of-two layout (yolov5m: 192, 384; yolov5x: 320)
+                                   (3, 192, 40, 24), (2, 320, 20, 20), (5, 384, 12, 20), (4, 192, 80, 80)],
                          ids=lambda s: 'x'.join(map(str, s)))
 def test_detect_level_in_one_kernel_equals_conv_then_decode(dev, shape):
     """y5_detect_f16 (head conv with the decode as its epilogue) against y5_conv_f16 followed by y5_detect_decode_f16 on
@@ -430,8 +432,8 @@ def test_detect_level_in_one_kernel_equals_conv_then_decode(dev, shape):
         if (ny * nx * no) % 8:
             assert rc == _lib.EINVAL, 'runs that are not 16-byte aligned belong to the two-kernel path'
             continue
-        persistent = v == lib.y5_detect_num_variants()  # the last variant: compiled for 128 and 256 input channels
-        if persistent and (Ci not in (128, 256) or no < 16):
+        persistent = v == lib.y5_detect_num_variants()  # the last variant: compiled for these input widths
+        if persistent and (Ci not in (128, 192, 256, 320, 384) or no < 16):
             assert rc == _lib.EINVAL
             taken += 1
             continue

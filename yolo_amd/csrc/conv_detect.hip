@@ -47,9 +47,13 @@ struct DetCfg {
 
 __device__ __forceinline__ int perm_row(int i) { return 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3); }  // see conv_csp.hip
 
-template <int KS, bool LW>  // LW: a ninth wave issues the input copies
+// LW: a ninth wave issues the input copies.  KSR <= KS: the head's real width (16 KSR input channels) inside staged rows laid
+// out for 16 KS (the swizzle needs a power-of-two number of slots per pixel): slots past it are never fetched - their lanes of
+// a copy ask for an out-of-range address - and K-steps past it are not multiplied.
+template <int KS, bool LW, int KSR = KS>
 __global__ __launch_bounds__(NTHC + (LW ? 64 : 0)) void detect_p_kernel(const DetArgs a, const DecodeArgs dec) {
     typedef DetCfg<KS> Cfg;
+    static_assert(KSR >= 1 && KSR <= KS, "real width inside the layout");
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int t = threadIdx.x, lane = t & 63, lr = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(NTHC + (LW ? 64 : 0)) void detect_p_kernel(const De
             if (d >= Cfg::PIECES) break;
             const int slot = d * 64 + lane, px = slot / Cfg::SLOTS, sp = slot % Cfg::SLOTS;
             const int s = sp ^ (px & 15);
-            dma16_buf(xr, px < np ? base + (unsigned)(px * a.x_ld * 2 + s * 16) : Y5_BUF_OOB, (unsigned)(d * 1024));
+            dma16_buf(xr, px < np && (KSR == KS || s < 2 * KSR) ? base + (unsigned)(px * a.x_ld * 2 + s * 16) : Y5_BUF_OOB, (unsigned)(d * 1024));
         }
     };
     if (LW && wave == NWC) {
@@ -86,9 +90,9 @@ __global__ __launch_bounds__(NTHC + (LW ? 64 : 0)) void detect_p_kernel(const De
     }
 
     // ---------------------------------------------------------------------- compute waves: output channels [32 wave, +32)
-    f16x8 wf[KS];
+    f16x8 wf[KSR];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) wf[ks] = *reinterpret_cast<const f16x8*>(a.w + (size_t)(wave * 32 + perm_row(lr)) * a.w_ld + ks * 16 + lh * 8);
+    for (int ks = 0; ks < KSR; ++ks) wf[ks] = *reinterpret_cast<const f16x8*>(a.w + (size_t)(wave * 32 + perm_row(lr)) * a.w_ld + ks * 16 + lh * 8);
     const int cbase = wave * 32 + 16 * lh;  // the lane's 16 channels: slots o0.. of anchor an0, then slots 0.. of anchor an0 + 1
     f32x4 bias[4];
 #pragma unroll
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(NTHC + (LW ? 64 : 0)) void detect_p_kernel(const De
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
+            for (int ks = 0; ks < KSR; ++ks)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], *reinterpret_cast<const f16x8*>(smem + px * Cfg::XROW + (((2 * ks + lh) ^ (px & 15)) << 4)), acc, 0, 0, 0);
             if (nt == 1) {
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // B: the input may be overwritten
@@ -190,17 +194,17 @@ int cu_count() {  // compute units of the current device (one persistent workgro
     return n;
 }
 
-template <int KS, bool LW>
+template <int KS, bool LW, int KSR = KS>
 int launch(const DetArgs& a, const DecodeArgs& dec, hipStream_t s) {
     typedef DetCfg<KS> Cfg;
     static std::atomic<unsigned long long> attr_set{0};
     const unsigned long long bit = 1ull << y5_current_device();
     if (!(attr_set.load() & bit)) {
-        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(detect_p_kernel<KS, LW>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
+        Y5_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(detect_p_kernel<KS, LW, KSR>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM));
         attr_set.fetch_or(bit);
     }
     const int cus = cu_count();
-    hipLaunchKernelGGL((detect_p_kernel<KS, LW>), dim3((unsigned)(a.ntiles < cus ? a.ntiles : cus)), dim3(NTHC + (LW ? 64 : 0)), (size_t)Cfg::SMEM, s, a, dec);
+    hipLaunchKernelGGL((detect_p_kernel<KS, LW, KSR>), dim3((unsigned)(a.ntiles < cus ? a.ntiles : cus)), dim3(NTHC + (LW ? 64 : 0)), (size_t)Cfg::SMEM, s, a, dec);
     Y5_LAUNCH_CHECK("detect_p_kernel");
     return Y5_OK;
 }
@@ -210,7 +214,9 @@ int launch(const DetArgs& a, const DecodeArgs& dec, hipStream_t s) {
 // The arguments were validated by y5_launch_detect.  Returns 0 when the level is outside what this kernel is compiled for
 // (then *rc is untouched), 1 after a launch attempt with its status in *rc.
 int y5_try_detect_persistent(const y5_conv_desc& c, const y5_decode_desc& d, hipStream_t s, int* rc) {
-    if (c.cin != 128 && c.cin != 256) return 0;  // 512 channels: 128 weight registers per lane, spills
+    // 128 and 256 input channels, and the widths of yolov5m / yolov5x heads inside those layouts' next power of two (192 in rows
+    // of 256, 320 and 384 in rows of 512); 512 channels would take 128 weight registers per lane and spill
+    if (c.cin != 128 && c.cin != 256 && c.cin != 192 && c.cin != 320 && c.cin != 384) return 0;
     DecodeArgs dec;
     size_t lds_bytes = 0;
     bool vec = false;
@@ -232,6 +238,7 @@ int y5_try_detect_persistent(const y5_conv_desc& c, const y5_decode_desc& d, hip
     a.div_no = make_fastdiv((unsigned)d.no);
     if ((TP * d.no) % 8) return 0;  // per-anchor blocks of the staged tiles start on 16-byte boundaries
     if (d.no < 16) return 0;        // a lane's 16 channels cross at most one anchor boundary
-    *rc = c.cin == 128 ? launch<8, true>(a, dec, s) : launch<16, false>(a, dec, s);
+    *rc = c.cin == 128 ? launch<8, true>(a, dec, s) : c.cin == 256 ? launch<16, false>(a, dec, s) : c.cin == 192 ? launch<16, false, 12>(a, dec, s)
+        : c.cin == 320 ? launch<32, false, 20>(a, dec, s) : launch<32, false, 24>(a, dec, s);
     return 1;
 }
