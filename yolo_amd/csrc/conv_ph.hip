@@ -4,16 +4,20 @@
 // GEMM view as in conv_igemm.hip: D[n][m] = sum_k W[n][k] * X[m][k], m = output pixel, n = output channel,
 // k = (tap, input channel) flattened - a 64-wide K-tile may span taps, so K = 9 * Cin is walked without per-tap padding
 // (Cin = 80 costs 12 K-tiles, not 18).  What differs is the schedule:
-//   * eight waves, each owning 128 pixels x 64 channels of the tile as 8 x 4 accumulators of v_mfma_f32_16x16x32
-//     (WM x WN waves: 256 x 256 tiles for wide layers, 512 x 128 for 128-channel ones);
-//   * a K-tile is staged as four half-tiles (pixel halves P0 / P1 = the rows of the waves' first / second 64 pixels,
-//     weight halves W0 / W1 = the rows of their first / second 32 channels) into two rings of four slots, by
-//     buffer_load ... lds issued by all waves, one half-tile per phase, up to 1.5 K-tiles ahead;
-//   * a K-tile is multiplied in four phases, one 64 x 32 quadrant of the wave tile each (16 MFMAs): fragment reads of
-//     the phase, one half-tile of DMAs, [barrier], 16 MFMAs, [barrier].  Waves 4-7 run one barrier behind waves 0-3, so
-//     on every SIMD one wave multiplies while its partner reads LDS and issues DMAs;
-//   * the only wait for DMAs is a counted s_waitcnt vmcnt(N) once per K-tile that leaves the three youngest half-tiles
-//     in flight; barriers are LDS-only.
+//   * eight waves as WM x WN, each owning MF x NF accumulators of v_mfma_f32_16x16x32 (up to 128 pixels x 64 channels: four
+//     fragment reads per eight multiplies); the compiled tiles run from 256 x 256 for wide layers to 512 x 80 for 80-channel ones;
+//   * a K-tile is staged as four half-tiles (pixel halves P0 / P1 = the rows of the waves' first / second MF halves,
+//     weight halves W0 / W1 likewise for NF) into a ring of four slots, by buffer_load ... lds issued by all waves, up to
+//     1.5 K-tiles ahead; 128-byte LDS rows are XOR-swizzled through the copies' source addresses;
+//   * a K-tile is multiplied in two phases (the accumulators of the first / second pixel half): fragment reads of the phase,
+//     the copies of one or three half-tiles, [barrier], the phase's MFMAs, [barrier].  Waves 4-7 run one barrier behind waves
+//     0-3, so on every SIMD one wave multiplies while its partner reads LDS and issues copies;
+//   * the only wait for copies is a counted s_waitcnt vmcnt(N) that leaves the youngest half-tiles in flight; barriers are
+//     LDS-only;
+//   * workgroups are persistent (one per compute unit, tiles in XCD-contiguous order); with Cin a multiple of 64 a K-tile
+//     lies in one tap and its tap offset and validity bit are scalar (UNI);
+//   * epilogue: post-ops in registers -> 16-bit tile in LDS -> 16-byte stores, the residual values fetched in batches of four
+//     chunks ahead of the store loop.
 // Hazards.  RAW: a half-tile is read no earlier than the phase after the counted wait that retired it, behind a barrier
 // every wave has passed after its own wait.  WAR: a slot is refilled one phase after its last read, and every phase
 // drains its reads (lgkmcnt(0)) before its first barrier.  K-tiles past the end are "issued" with out-of-range offsets
