@@ -193,13 +193,14 @@ def pad8(c):
 
 
 def _irregular_widths(model):
-    """True when some convolution of the model has a channel count that is not a multiple of 32 (the Detect convolutions
-    and the image side of the first layer aside): a pruned channel plan."""
+    """True when some convolution of the model has a channel count that is not a multiple of 16 (the Detect convolutions
+    and the image side of the first layer aside): a pruned channel plan.  The shipped graphs, yolov5m's 48 and yolov5x's 80
+    channels included, are regular in this sense and are planned once."""
     from yolo_amd.models.yolo import Detect
     head = model.model[-1] if isinstance(model.model[-1], Detect) else None
     skip = set(id(m) for m in head.m) if head is not None else set()
     for m in model.modules():
-        if isinstance(m, nn.Conv2d) and id(m) not in skip and (m.out_channels % 32 or (m.in_channels % 32 and m.in_channels > 16)):
+        if isinstance(m, nn.Conv2d) and id(m) not in skip and (m.out_channels % 16 or (m.in_channels % 16 and m.in_channels > 16)):
             return True
     return False
 
